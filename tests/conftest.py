@@ -1,0 +1,32 @@
+import ast
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_cases():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not p.endswith("setup.npz"))
+
+
+def load_golden(name):
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    if "meta" in d:
+        d["meta"] = ast.literal_eval(str(d["meta"]))
+    return d
+
+
+@pytest.fixture(scope="session")
+def setup_vectors():
+    return dict(np.load(os.path.join(GOLDEN, "setup.npz"), allow_pickle=False))

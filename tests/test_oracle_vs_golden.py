@@ -1,0 +1,103 @@
+"""The CPU oracle (oracle/cvvdp_oracle.py) against vectors produced by the real reference
+(oracle/make_goldens.py).  This is what pins the oracle; the GPU tests then compare the HIP
+path against the oracle and against the same vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cases, load_golden
+from oracle import cvvdp_oracle as orc
+
+
+def _oracle_for(meta, keep=False):
+    return orc.Oracle(display_name=meta.get("display"), heatmap=meta["heatmap"], temp_padding=meta["temp_padding"], keep=keep,
+                      photometry=meta.get("custom_photometry"), geometry=meta.get("custom_geometry")) \
+        if "custom_photometry" not in meta else \
+        orc.Oracle(display_name=None, heatmap=meta["heatmap"], temp_padding=meta["temp_padding"], keep=keep,
+                   photometry=meta["custom_photometry"], geometry=meta["custom_geometry"])
+
+
+def _inputs(g):
+    t, r = g["test"], g["ref"]
+    if t.dtype == np.float16:  # fp16 cases were fed to the reference as torch tensors
+        t, r = torch.tensor(t), torch.tensor(r)
+    return t, r
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_end_to_end(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    o = _oracle_for(meta)
+    t, r = _inputs(g)
+    jod, stats = o.predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+    assert abs(o.ppd - float(g["ppd"])) < 1e-9
+    np.testing.assert_allclose(stats["rho_band"], g["rho_band"], rtol=1e-12)
+    np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(jod.numpy(), g["jod"], atol=2e-5)
+    if "taps" in g:
+        np.testing.assert_allclose(np.stack([x.numpy() for x in o.taps]), g["taps"], atol=1e-8)
+    if "heatmap" in g:
+        hm = stats["heatmap"].numpy().astype(np.float32)
+        ref = g["heatmap"].astype(np.float32)
+        assert hm.shape == ref.shape
+        # fp16 output: allow one fp16 ulp on a tiny fraction of pixels (rounding of equal-to-1e-7 fp32 values)
+        bad = np.abs(hm - ref) > 2e-3
+        assert bad.mean() < 1e-4, bad.mean()
+        assert np.abs(hm - ref).max() < 5e-3
+
+
+@pytest.mark.parametrize("name", ["img_u8_64x96_fhd_thr", "vid_u8_72x128x12_60_fhd"])
+def test_intermediates(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    o = _oracle_for(meta, keep=True)
+    t, r = _inputs(g)
+    o.predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+    d = o.dbg
+    np.testing.assert_allclose(d["R"].numpy(), g["i_R"], rtol=1e-6, atol=1e-6)
+    L = len(d["gpyr"])
+    for i in range(L):
+        np.testing.assert_allclose(d["gpyr"][i].numpy(), g["i_g%d" % i], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(d["contrast"][i].numpy(), g["i_c%d" % i], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(d["logL"][i].numpy(), g["i_l%d" % i], rtol=1e-6, atol=1e-6)
+    for i in range(L - 1):  # masking is not applied to the baseband
+        np.testing.assert_allclose(d["S"][i].numpy(), g["i_S%d" % i], rtol=1e-5)
+        np.testing.assert_allclose(d["D"][i].numpy(), g["i_D%d" % i], rtol=1e-4, atol=1e-6)
+
+
+def test_setup_vectors(setup_vectors):
+    s = setup_vectors
+    o = orc.Oracle("standard_4k")
+    for fps in (24, 25, 30, 50, 60, 120):
+        np.testing.assert_allclose(np.stack([x.numpy() for x in o.temporal_filters(fps)]), s["taps_%d" % fps], atol=1e-8)
+    for disp in ("standard_4k", "standard_hdr_pq"):
+        d = orc.Display(disp)
+        np.testing.assert_array_equal(d.dkl_matrix().numpy(), s["dkl_" + disp])
+        np.testing.assert_allclose(np.array(d.black_level()), s["black_" + disp], rtol=1e-15)
+    for i, rho in enumerate(s["csf_rhos"]):
+        for j, (oo, cc) in enumerate(((0, 0), (0, 1), (0, 2), (1, 0))):
+            np.testing.assert_allclose(o.csf.row(float(rho), oo, cc).numpy(), s["csf_rows"][i, j], rtol=1e-6, atol=1e-7)
+    q = torch.tensor(s["csf_query"])
+    for j, (oo, cc) in enumerate(((0, 0), (0, 1), (0, 2), (1, 0))):
+        np.testing.assert_allclose(o.csf.sensitivity(o.csf.row(3.0424, oo, cc), q).numpy(), s["csf_S"][j], rtol=1e-6)
+    for row, disp in zip(s["band_sizes"], s["band_displays"]):
+        W, H, ppd, nb = int(row[0]), int(row[1]), row[2], int(row[3])
+        d = orc.Display(str(disp))
+        assert abs(d.ppd - ppd) < 1e-9
+        h, fr = orc.band_frequencies(W, H, d.ppd)
+        assert h + 1 == nb
+        np.testing.assert_allclose(fr, row[4:4 + nb], rtol=1e-12)
+
+
+def test_photometry_ramps(setup_vectors):
+    s = setup_vectors
+    ramp = torch.tensor(s["fwd_ramp"])
+    for disp in ("standard_4k", "standard_hdr_pq", "standard_hdr_hlg", "standard_hdr_linear", "standard_phone"):
+        d = orc.Display(disp)
+        inp = ramp * (1000.0 if disp == "standard_hdr_linear" else 1.0)
+        np.testing.assert_allclose(d.to_dkl(inp).numpy(), s["fwd_" + disp], rtol=1e-6, atol=1e-6)
+    d = orc.Display(photometry=dict(Y_peak=120, contrast=800, source_colorspace="Adobe RGB (1998)", E_ambient=80), geometry=dict(resolution=(1920, 1200), ppd=60))
+    np.testing.assert_allclose(d.to_dkl(ramp).numpy(), s["fwd_gamma22"], rtol=1e-6, atol=1e-6)
+    d = orc.Display(photometry=dict(Y_peak=300, contrast=2000, source_colorspace="sRGB", E_ambient=10, exposure=0.7), geometry=dict(resolution=(1920, 1200), ppd=60))
+    np.testing.assert_allclose(d.to_dkl(ramp).numpy(), s["fwd_srgb_exp07"], rtol=1e-6, atol=1e-6)

@@ -1,0 +1,8 @@
+"""colorvideovdp_amd: MI355X-native compute core for the ColorVideoVDP metric behind the reference's
+Python API (`cvvdp.predict`, `cvvdp.predict_video_source`, heat maps, distograms)."""
+from .cvvdp_metric import cvvdp
+from .display_model import vvdp_display_geometry, vvdp_display_photo_eotf, vvdp_display_photometry
+from .video_source import reshuffle_dims, video_source, video_source_array
+from .vq_metric import register_metric, vq_exception, vq_metric, vq_metric_dict
+
+__version__ = "0.1.0"

@@ -1,0 +1,441 @@
+// C ABI of the compute core (include/cvvdp_hip.h): handle, workspace planning, launch sequencing.
+// No device memory is allocated here; everything lives in the caller's workspace buffer.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace cvvdp;
+
+namespace {
+
+struct Level {
+  int H = 0, W = 0;
+  int64_t P = 0;
+  size_t g_off = 0, heat_off = 0, dd_off = 0;  // float offsets into the workspace
+  int n_strip = 1, n_seg = 1, seg_h = 1;
+  bool blur = false;
+};
+
+struct ProfEvent { hipEvent_t a, b; int cat; };
+
+}  // namespace
+
+struct cvvdp_handle {
+  cvvdp_params p{};
+  cvvdp_clip c{};
+  bool configured = false;
+  int nch = 4, L = 0, items_cap = 0;
+  std::vector<Level> lv;
+  size_t ring_off = 0, partial_off = 0, q_off = 0, hstats_off = 0, hcurve_off = 0;
+  size_t ws_floats = 0;
+  float* ws = nullptr;
+  int last_items = 0;
+  std::string err;
+  bool prof = false;
+  std::vector<ProfEvent> events;
+  size_t events_used = 0;
+};
+
+namespace {
+
+int fail(cvvdp_handle* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf;
+  return code;
+}
+
+size_t align_up(size_t n_floats) { return (n_floats + 63) & ~size_t(63); }  // 256-byte granules
+
+int check_launch(cvvdp_handle* h, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, CVVDP_E_HIP, "%s: %s", what, hipGetErrorString(e));
+  return CVVDP_OK;
+}
+
+struct ProfScope {
+  cvvdp_handle* h; hipStream_t s; ProfEvent* ev = nullptr;
+  ProfScope(cvvdp_handle* h_, int cat, hipStream_t s_) : h(h_), s(s_) {
+    if (!h->prof) return;
+    if (h->events_used == h->events.size()) {
+      ProfEvent e{};
+      if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+      h->events.push_back(e);
+    }
+    ev = &h->events[h->events_used++];
+    ev->cat = cat;
+    (void)hipEventRecord(ev->a, s);
+  }
+  ~ProfScope() { if (ev) (void)hipEventRecord(ev->b, s); }
+};
+
+void fill_csf(const cvvdp_handle* h, int level, float* lut) {
+  std::memcpy(lut, h->c.csf_rows + (size_t)level * 4 * CVVDP_CSF_NODES, sizeof(float) * 4 * CVVDP_CSF_NODES);
+}
+
+void heat_weights(const cvvdp_handle* h, bool baseband, float* w) {
+  // cvvdp_metric.py:728-731
+  const float t_int = h->c.is_video ? 1.0f : h->p.image_int;
+  for (int c = 0; c < 4; ++c) {
+    w[c] = h->p.ch_w[c] * t_int;
+    if (baseband) w[c] = w[c] * h->p.baseband_weight[c];
+  }
+}
+
+int run_pyramid_and_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, hipStream_t s) {
+  const int B = h->c.batch, items = n_frames * B, L = h->L, nch = h->nch;
+  const float K[5] = {0.25f - 0.4f / 2.0f, 0.25f, 0.4f, 0.25f, 0.25f - 0.4f / 2.0f};  // lpyr_dec.py:179
+  const bool heat = h->c.heatmap != CVVDP_HEATMAP_NONE;
+  for (int l = 0; l + 1 < L; ++l) {
+    ProfScope ps(h, CVVDP_PROF_REDUCE, s);
+    ReduceArgs r{};
+    r.in = h->ws + h->lv[l].g_off;
+    r.out = h->ws + h->lv[l + 1].g_off;
+    r.H = h->lv[l].H; r.W = h->lv[l].W; r.Ho = h->lv[l + 1].H; r.Wo = h->lv[l + 1].W;
+    r.n_img = items; r.img_cap = h->items_cap; r.n_planes = 2 * nch;
+    for (int i = 0; i < 5; ++i) r.k[i] = K[i];
+    launch_reduce(r, s);
+  }
+  if (int e = check_launch(h, "reduce")) return e;
+  for (int l = 0; l + 1 < L; ++l) {
+    const Level& lv = h->lv[l];
+    ProfScope ps(h, l == 0 ? CVVDP_PROF_BAND0 : CVVDP_PROF_BAND_REST, s);
+    BandArgs a{};
+    a.g = h->ws + lv.g_off;
+    a.gc = h->ws + h->lv[l + 1].g_off;
+    a.H = lv.H; a.W = lv.W; a.Hc = h->lv[l + 1].H; a.Wc = h->lv[l + 1].W;
+    a.items = items; a.items_cap = h->items_cap; a.nch = nch;
+    a.seg_h = lv.seg_h; a.n_seg = lv.n_seg; a.n_strip = lv.n_strip;
+    a.band_mul = (l == 0) ? 1.0f : 2.0f;  // lpyr_dec.py:60-66 (baseband handled separately)
+    fill_csf(h, l, a.lut);
+    a.logL_first = h->p.csf_logL_first; a.logL_last = h->p.csf_logL_last;
+    a.sens_mul = h->p.sens_mul;
+    for (int c = 0; c < 4; ++c) {
+      a.ch_gain[c] = h->p.ch_gain[c];
+      a.q[c] = h->p.mask_q[c];
+      a.eps_q[c] = std::pow(kEps, h->p.mask_q[c]);
+    }
+    a.mask_c10 = h->p.mask_c10; a.mask_p = h->p.mask_p; a.eps_p = std::pow(kEps, h->p.mask_p);
+    for (int i = 0; i < 16; ++i) a.xw[i] = h->p.xcm[i];
+    a.dmax = h->p.d_max10;
+    for (int i = 0; i < 13; ++i) a.blur[i] = h->p.blur_taps[i];
+    a.kx[0] = K[0] * 2.0f; a.kx[1] = K[2] * 2.0f; a.kx[2] = K[1] * 2.0f;
+    a.partial = h->ws + h->partial_off;
+    a.dchr = heat ? h->ws + lv.heat_off : nullptr;
+    heat_weights(h, false, a.hw);
+    a.beta_tch = h->p.beta_tch; a.eps_btch = std::pow(kEps, h->p.beta_tch); a.eps_inv_btch = std::pow(kEps, 1.0f / h->p.beta_tch);
+    a.ddump = h->c.debug_dump ? h->ws + lv.dd_off : nullptr;
+    launch_band(a, lv.blur, s);
+    FinalizeArgs f{};
+    f.partial = a.partial; f.items = items; f.nblk = lv.n_strip * lv.n_seg; f.nch = nch; f.P = (int)lv.P;
+    f.q_out = h->ws + h->q_off; f.q_frames = h->c.n_frames; f.q_levels = L; f.q_frame_offset = q_frame_offset;
+    f.level = l; f.batch = B;
+    launch_finalize(f, s);
+  }
+  if (int e = check_launch(h, "band")) return e;
+  {
+    const Level& lv = h->lv[L - 1];
+    ProfScope ps(h, CVVDP_PROF_BAND_REST, s);
+    BaseArgs b{};
+    b.g = h->ws + lv.g_off; b.H = lv.H; b.W = lv.W; b.items = items; b.items_cap = h->items_cap; b.nch = nch;
+    fill_csf(h, L - 1, b.lut);
+    b.logL_first = h->p.csf_logL_first; b.logL_last = h->p.csf_logL_last; b.sens_mul = h->p.sens_mul;
+    b.q_out = h->ws + h->q_off; b.q_frames = h->c.n_frames; b.q_levels = L; b.q_frame_offset = q_frame_offset;
+    b.level = L - 1; b.batch = B;
+    b.dchr = heat ? h->ws + lv.heat_off : nullptr;
+    heat_weights(h, true, b.hw);
+    b.beta_tch = h->p.beta_tch; b.eps_btch = std::pow(kEps, h->p.beta_tch); b.eps_inv_btch = std::pow(kEps, 1.0f / h->p.beta_tch);
+    b.ddump = h->c.debug_dump ? h->ws + lv.dd_off : nullptr;
+    launch_baseband(b, s);
+  }
+  if (int e = check_launch(h, "baseband")) return e;
+  if (heat) {  // lpyr_dec_2.reconstruct, lpyr_dec.py:328-335: coarse to fine, in place
+    ProfScope ps(h, CVVDP_PROF_HEATMAP, s);
+    for (int l = L - 2; l >= 0; --l) {
+      ExpandAddArgs e{};
+      e.fine = h->ws + h->lv[l].heat_off; e.coarse = h->ws + h->lv[l + 1].heat_off;
+      e.H = h->lv[l].H; e.W = h->lv[l].W; e.Hc = h->lv[l + 1].H; e.Wc = h->lv[l + 1].W; e.n_img = items;
+      e.kx[0] = K[0] * 2.0f; e.kx[1] = K[2] * 2.0f; e.kx[2] = K[1] * 2.0f;
+      launch_expand_add(e, s);
+    }
+    if (int e = check_launch(h, "heat reconstruct")) return e;
+  }
+  h->last_items = items;
+  return CVVDP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cvvdp_abi_version(void) { return CVVDP_ABI_VERSION; }
+
+void cvvdp_struct_sizes(int32_t* params_bytes, int32_t* clip_bytes) {
+  if (params_bytes) *params_bytes = (int32_t)sizeof(cvvdp_params);
+  if (clip_bytes) *clip_bytes = (int32_t)sizeof(cvvdp_clip);
+}
+
+int cvvdp_create(const cvvdp_params* params, cvvdp_handle** out) {
+  if (!params || !out) return CVVDP_E_ARG;
+  cvvdp_handle* h = new (std::nothrow) cvvdp_handle();
+  if (!h) return CVVDP_E_ARG;
+  h->p = *params;
+  *out = h;
+  return CVVDP_OK;
+}
+
+void cvvdp_destroy(cvvdp_handle* h) {
+  if (!h) return;
+  for (auto& e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  delete h;
+}
+
+const char* cvvdp_last_error(const cvvdp_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
+  if (!h || !clip) return CVVDP_E_ARG;
+  const cvvdp_clip& c = *clip;
+  if (c.batch < 1 || c.height < 2 || c.width < 2 || c.n_frames < 1) return fail(h, CVVDP_E_ARG, "bad clip geometry");
+  if (c.channels != 1 && c.channels != 3) return fail(h, CVVDP_E_ARG, "channels must be 1 or 3");
+  if (c.n_levels < 1 || c.n_levels > CVVDP_MAX_LEVELS) return fail(h, CVVDP_E_ARG, "n_levels out of range");
+  if (c.is_video) {
+    if (c.filter_len < 1 || c.filter_len > CVVDP_MAX_FILTER_LEN) return fail(h, CVVDP_E_UNSUPPORTED, "filter_len %d unsupported (max %d)", c.filter_len, CVVDP_MAX_FILTER_LEN);
+    if (c.block_frames < 1 || c.filter_len - 1 + c.block_frames > CVVDP_MAX_WINDOW) return fail(h, CVVDP_E_ARG, "block_frames out of range");
+    if (c.ring_slots < c.filter_len - 1 + c.block_frames || c.ring_slots > 32767) return fail(h, CVVDP_E_ARG, "ring_slots too small");
+  }
+  if (c.heatmap != CVVDP_HEATMAP_NONE && c.batch != 1) return fail(h, CVVDP_E_UNSUPPORTED, "heat maps need batch == 1");
+  h->c = c;
+  h->nch = c.is_video ? 4 : 3;
+  h->L = c.n_levels;
+  h->items_cap = (c.is_video ? c.block_frames : 1) * c.batch;
+  h->lv.assign(h->L, Level());
+  int H = c.height, W = c.width;
+  const int pad = h->p.blur_radius;
+  for (int l = 0; l < h->L; ++l) {
+    Level& lv = h->lv[l];
+    lv.H = H; lv.W = W; lv.P = (int64_t)H * W;
+    lv.blur = pad > 0 && H > pad && W > pad;
+    const int sw = lv.blur ? 256 - 2 * pad : 256;
+    lv.n_strip = (W + sw - 1) / sw;
+    lv.n_seg = (H + 127) / 128;
+    lv.seg_h = (H + lv.n_seg - 1) / lv.n_seg;
+    if (l + 1 < h->L && (H < 2 || W < 2)) return fail(h, CVVDP_E_ARG, "pyramid too deep for %dx%d", c.width, c.height);
+    H = (H + 1) / 2; W = (W + 1) / 2;
+  }
+  if (pad != 0 && pad != 6) return fail(h, CVVDP_E_UNSUPPORTED, "blur radius %d unsupported", pad);
+  // ---- workspace plan (float offsets)
+  size_t off = 0;
+  const size_t P0 = (size_t)h->lv[0].P;
+  h->ring_off = off;
+  if (c.is_video) off += align_up((size_t)2 * 3 * c.ring_slots * c.batch * P0);
+  for (auto& lv : h->lv) { lv.g_off = off; off += align_up((size_t)2 * h->nch * h->items_cap * lv.P); }
+  size_t pmax = 0;
+  for (auto& lv : h->lv) pmax = std::max(pmax, (size_t)h->items_cap * lv.n_strip * lv.n_seg * 4);
+  h->partial_off = off; off += align_up(pmax);
+  h->q_off = off; off += align_up((size_t)c.batch * h->nch * c.n_frames * h->L);
+  if (c.heatmap != CVVDP_HEATMAP_NONE) {
+    for (auto& lv : h->lv) { lv.heat_off = off; off += align_up((size_t)h->items_cap * lv.P); }
+    h->hstats_off = off; off += align_up((size_t)h->items_cap * kHeatStatsWords);
+    h->hcurve_off = off; off += align_up((size_t)h->items_cap * kHeatCurveWords);
+  }
+  if (c.debug_dump) for (auto& lv : h->lv) { lv.dd_off = off; off += align_up((size_t)4 * h->items_cap * lv.P); }
+  h->ws_floats = off;
+  h->ws = nullptr;
+  h->configured = true;
+  h->last_items = 0;
+  return CVVDP_OK;
+}
+
+size_t cvvdp_workspace_bytes(const cvvdp_handle* h) { return (h && h->configured) ? h->ws_floats * sizeof(float) : 0; }
+
+int cvvdp_bind_workspace(cvvdp_handle* h, void* dev, size_t bytes) {
+  if (!h || !h->configured) return fail(h, CVVDP_E_STATE, "configure first");
+  if (!dev || bytes < h->ws_floats * sizeof(float)) return fail(h, CVVDP_E_ARG, "workspace too small: need %zu bytes", h->ws_floats * sizeof(float));
+  if (reinterpret_cast<uintptr_t>(dev) % 256) return fail(h, CVVDP_E_ARG, "workspace must be 256-byte aligned");
+  h->ws = static_cast<float*>(dev);
+  return CVVDP_OK;
+}
+
+int cvvdp_put_frames(cvvdp_handle* h, const void* t, const void* r, int32_t dtype, const int64_t st[5], const int64_t sr[5],
+                     int32_t first_slot, int32_t n_frames, void* stream) {
+  if (!h || !h->ws) return fail(h, CVVDP_E_STATE, "no workspace bound");
+  if (!t || !r || !st || !sr || n_frames < 1) return fail(h, CVVDP_E_ARG, "bad frame arguments");
+  if (dtype < CVVDP_U8 || dtype > CVVDP_F32_DKL) return fail(h, CVVDP_E_UNSUPPORTED, "dtype %d unsupported", dtype);
+  const cvvdp_clip& c = h->c;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  PhotoArgs a{};
+  a.src[0] = t; a.src[1] = r;
+  const int64_t* S[2] = {st, sr};
+  for (int k = 0; k < 2; ++k) { a.sb[k] = S[k][0]; a.sc[k] = S[k][1]; a.sf[k] = S[k][2]; a.sh[k] = S[k][3]; a.sw[k] = S[k][4]; }
+  a.dtype = dtype; a.channels = c.channels; a.H = c.height; a.W = c.width; a.batch = c.batch; a.n_frames = n_frames;
+  a.eotf = h->p.eotf; a.Y_peak = h->p.Y_peak; a.Y_black = h->p.Y_black; a.Y_refl = h->p.Y_refl;
+  a.exposure = h->p.exposure; a.gamma = h->p.gamma;
+  a.scale = (float)((double)h->p.Y_peak - (double)h->p.Y_black);
+  a.lin_lo = std::max(0.005f, h->p.Y_black);
+  a.hlg_c = (float)(0.5 - 0.17883277 * std::log(4.0 * 0.17883277));
+  for (int i = 0; i < 9; ++i) a.m[i] = h->p.rgb2dkl[i];
+  const int64_t P0 = h->lv[0].P;
+  if (c.is_video) {
+    if (n_frames > c.ring_slots) return fail(h, CVVDP_E_ARG, "more frames than ring slots");
+    a.dst = h->ws + h->ring_off;
+    a.d_b = P0; a.d_slot = (int64_t)c.batch * P0; a.d_ch = (int64_t)c.ring_slots * a.d_slot; a.d_side = 3 * a.d_ch;
+    a.first_slot = ((first_slot % c.ring_slots) + c.ring_slots) % c.ring_slots; a.n_slots = c.ring_slots;
+  } else {
+    if (n_frames != 1) return fail(h, CVVDP_E_ARG, "an image has one frame");
+    a.dst = h->ws + h->lv[0].g_off;
+    a.d_b = P0; a.d_slot = 0; a.d_side = (int64_t)h->items_cap * P0; a.d_ch = 2 * a.d_side;
+    a.first_slot = 0; a.n_slots = 1;
+  }
+  {
+    ProfScope ps(h, CVVDP_PROF_PHOTOMETRY, s);
+    launch_photometry(a, s);
+  }
+  return check_launch(h, "photometry");
+}
+
+int cvvdp_process_block(cvvdp_handle* h, const int32_t* window_slots, int32_t n_frames, int32_t q_frame_offset, void* stream) {
+  if (!h || !h->ws) return fail(h, CVVDP_E_STATE, "no workspace bound");
+  const cvvdp_clip& c = h->c;
+  if (!c.is_video) return fail(h, CVVDP_E_STATE, "configured for an image");
+  if (!window_slots || n_frames < 1 || n_frames > c.block_frames) return fail(h, CVVDP_E_ARG, "n_frames out of range");
+  if (q_frame_offset < 0 || q_frame_offset + n_frames > c.n_frames) return fail(h, CVVDP_E_ARG, "frame offset out of range");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int fl = c.filter_len;
+  FirArgs f{};
+  const int64_t P0 = h->lv[0].P;
+  f.ring = h->ws + h->ring_off;
+  f.r_b = P0; f.r_slot = (int64_t)c.batch * P0; f.r_ch = (int64_t)c.ring_slots * f.r_slot; f.r_side = 3 * f.r_ch;
+  f.out = h->ws + h->lv[0].g_off; f.o_plane = (int64_t)h->items_cap * P0;
+  f.P = (int)P0; f.batch = c.batch; f.n_frames = n_frames; f.fl = fl;
+  for (int ch = 0; ch < 4; ++ch)
+    for (int k = 0; k < fl; ++k) f.taps[ch * CVVDP_MAX_FILTER_LEN + k] = c.taps[ch * CVVDP_MAX_FILTER_LEN + (fl - 1 - k)];  // F.flip(0), :556
+  for (int k = 0; k < fl - 1 + n_frames; ++k) {
+    if (window_slots[k] < 0 || window_slots[k] >= c.ring_slots) return fail(h, CVVDP_E_ARG, "window slot %d out of range", window_slots[k]);
+    f.slots[k] = (int16_t)window_slots[k];
+  }
+  {
+    ProfScope ps(h, CVVDP_PROF_FIR, s);
+    launch_fir(f, s);
+  }
+  if (int e = check_launch(h, "temporal fir")) return e;
+  return run_pyramid_and_bands(h, n_frames, q_frame_offset, s);
+}
+
+int cvvdp_process_image(cvvdp_handle* h, void* stream) {
+  if (!h || !h->ws) return fail(h, CVVDP_E_STATE, "no workspace bound");
+  if (h->c.is_video) return fail(h, CVVDP_E_STATE, "configured for video");
+  return run_pyramid_and_bands(h, 1, 0, static_cast<hipStream_t>(stream));
+}
+
+int cvvdp_get_q_per_ch(cvvdp_handle* h, float* dev_out, void* stream) {
+  if (!h || !h->ws) return fail(h, CVVDP_E_STATE, "no workspace bound");
+  if (!dev_out) return fail(h, CVVDP_E_ARG, "null output");
+  const size_t n = (size_t)h->c.batch * h->nch * h->c.n_frames * h->L;
+  hipError_t e = hipMemcpyAsync(dev_out, h->ws + h->q_off, n * sizeof(float), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(h, CVVDP_E_HIP, "copy Q_per_ch: %s", hipGetErrorString(e));
+  return CVVDP_OK;
+}
+
+int cvvdp_pool_jod(cvvdp_handle* h, const float* q, int32_t B, int32_t C, int32_t F, int32_t bands, float* jod, void* stream) {
+  if (!h) return CVVDP_E_ARG;
+  if (!q || !jod || B < 1 || C < 1 || C > 4 || F < 1 || bands < 1) return fail(h, CVVDP_E_ARG, "bad pooling arguments");
+  PoolArgs a{};
+  a.q = q; a.B = B; a.C = C; a.F = F; a.L = bands;
+  for (int c = 0; c < 4; ++c) { a.ch_w[c] = h->p.ch_w[c]; a.bb_w[c] = h->p.baseband_weight[c]; }
+  a.beta_sch = h->p.beta_sch; a.beta_tch = h->p.beta_tch; a.beta_t = h->p.beta_t;
+  a.jod_a = h->p.jod_a; a.jod_exp = h->p.jod_exp; a.image_int = h->p.image_int;
+  a.jod = jod;
+  launch_pool(a, static_cast<hipStream_t>(stream));
+  return check_launch(h, "pool");
+}
+
+int cvvdp_get_heatmap(cvvdp_handle* h, int32_t n_frames, void* dev_out_f16, void* stream) {
+  if (!h || !h->ws) return fail(h, CVVDP_E_STATE, "no workspace bound");
+  if (h->c.heatmap == CVVDP_HEATMAP_NONE) return fail(h, CVVDP_E_STATE, "heat map not enabled");
+  if (!dev_out_f16 || n_frames < 1 || n_frames * h->c.batch != h->last_items) return fail(h, CVVDP_E_ARG, "n_frames does not match the last block");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HeatArgs a{};
+  a.recon = h->ws + h->lv[0].heat_off;
+  a.ctx = h->ws + h->lv[0].g_off;  // plane 0 = test Y-sustained (cvvdp_metric.py:400)
+  a.P = (int)h->lv[0].P; a.items = h->last_items; a.mode = h->c.heatmap;
+  a.jod_a = h->p.jod_a; a.jod_exp = h->p.jod_exp;
+  a.stats = reinterpret_cast<uint32_t*>(h->ws + h->hstats_off);
+  a.curve = h->ws + h->hcurve_off;
+  a.out = dev_out_f16;
+  ProfScope ps(h, CVVDP_PROF_HEATMAP, s);
+  if (h->c.heatmap == CVVDP_HEATMAP_RAW) {
+    launch_heat_raw(a, s);
+  } else {
+    // colour maps of visualize_diff_map.py:59-94, normalised by their luminance
+    static const float thr[5][3] = {{0.2f, 0.2f, 1.0f}, {0.2f, 1.0f, 1.0f}, {0.2f, 1.0f, 0.2f}, {1.0f, 1.0f, 0.2f}, {1.0f, 0.2f, 0.2f}};
+    static const float sup[3][3] = {{0.2f, 1.0f, 1.0f}, {1.0f, 1.0f, 1.0f}, {1.0f, 1.0f, 0.2f}};
+    const bool is_thr = h->c.heatmap == CVVDP_HEATMAP_THRESHOLD;
+    a.n_nodes = is_thr ? 5 : 3;
+    for (int k = 0; k < a.n_nodes; ++k) {
+      const float* row = is_thr ? thr[k] : sup[k];
+      volatile float l = row[0] * 0.212656f;
+      volatile float l1 = row[1] * 0.715158f;
+      volatile float l2 = row[2] * 0.072186f;
+      volatile float lum = l + l1;
+      lum = lum + l2;
+      for (int ch = 0; ch < 3; ++ch) a.cch[k * 3 + ch] = row[ch] / (lum + 0.0001f);
+      a.cin[k] = is_thr ? (0.25f * k) * 0.1f : (0.5f * k) * 0.3f;
+    }
+    launch_heat_colour(a, s);
+  }
+  return check_launch(h, "heat map");
+}
+
+int cvvdp_debug_buffer(cvvdp_handle* h, int32_t which, int32_t level, void** dev_ptr, size_t* n_floats) {
+  if (!h || !h->ws || !dev_ptr || !n_floats) return fail(h, CVVDP_E_STATE, "no workspace bound");
+  if (level < 0 || level >= h->L) return fail(h, CVVDP_E_ARG, "bad level");
+  const Level& lv = h->lv[level];
+  switch (which) {
+    case CVVDP_BUF_RING:
+      if (!h->c.is_video) return fail(h, CVVDP_E_STATE, "no ring for images");
+      *dev_ptr = h->ws + h->ring_off; *n_floats = (size_t)2 * 3 * h->c.ring_slots * h->c.batch * h->lv[0].P; break;
+    case CVVDP_BUF_GPYR: *dev_ptr = h->ws + lv.g_off; *n_floats = (size_t)2 * h->nch * h->items_cap * lv.P; break;
+    case CVVDP_BUF_DDUMP:
+      if (!h->c.debug_dump) return fail(h, CVVDP_E_STATE, "debug_dump not enabled");
+      *dev_ptr = h->ws + lv.dd_off; *n_floats = (size_t)4 * h->items_cap * lv.P; break;
+    case CVVDP_BUF_HEAT:
+      if (h->c.heatmap == CVVDP_HEATMAP_NONE) return fail(h, CVVDP_E_STATE, "heat map not enabled");
+      *dev_ptr = h->ws + lv.heat_off; *n_floats = (size_t)h->items_cap * lv.P; break;
+    case CVVDP_BUF_Q: *dev_ptr = h->ws + h->q_off; *n_floats = (size_t)h->c.batch * h->nch * h->c.n_frames * h->L; break;
+    default: return fail(h, CVVDP_E_ARG, "unknown buffer");
+  }
+  return CVVDP_OK;
+}
+
+int cvvdp_profile_enable(cvvdp_handle* h, int32_t enable) {
+  if (!h) return CVVDP_E_ARG;
+  h->prof = enable != 0;
+  h->events_used = 0;
+  return CVVDP_OK;
+}
+
+int cvvdp_profile_read(cvvdp_handle* h, double total_ms[CVVDP_PROF_N], int32_t n_launches[CVVDP_PROF_N]) {
+  if (!h || !total_ms || !n_launches) return CVVDP_E_ARG;
+  for (int i = 0; i < CVVDP_PROF_N; ++i) { total_ms[i] = 0.0; n_launches[i] = 0; }
+  for (size_t i = 0; i < h->events_used; ++i) {
+    ProfEvent& e = h->events[i];
+    if (hipEventSynchronize(e.b) != hipSuccess) return fail(h, CVVDP_E_HIP, "event sync failed");
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) return fail(h, CVVDP_E_HIP, "event elapsed failed");
+    total_ms[e.cat] += ms;
+    n_launches[e.cat] += 1;
+  }
+  h->events_used = 0;
+  return CVVDP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+// K9/K10: heat-map finishing.
+//   raw:      1 - met2jod(reconstructed difference)/10            cvvdp_metric.py:744, :398
+//   coloured: visualize_diff_map (visualize_diff_map.py:48-106): log-luminance context image
+//             (:17-20), histogram tone curve (:23-45, 1024 bins, p^(1/3) cumulative), piecewise-linear
+//             colour map (interp.py:22-31,81-89), fp16 output.
+// Tone-map statistics are per frame (block of 1 = the reference's CPU behaviour).
+#include "kernels.h"
+#include <hip/hip_fp16.h>
+
+namespace cvvdp {
+
+__device__ __forceinline__ float heat_value(float q, float jod_a, float jod_exp) {
+  float jod;
+  if (q <= 0.1f) jod = 10.0f - jod_a * powf(0.1f, jod_exp - 1.0f) * q;   // met2jod, cvvdp_metric.py:646-658
+  else jod = 10.0f - jod_a * powf(q, jod_exp);
+  return 1.0f - jod / 10.0f;
+}
+
+__global__ __launch_bounds__(256) void k_heat_raw(HeatArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)a.items * a.P) return;
+  reinterpret_cast<__half*>(a.out)[i] = __float2half(heat_value(a.recon[i], a.jod_a, a.jod_exp));
+}
+
+void launch_heat_raw(const HeatArgs& a, hipStream_t s) {
+  const int64_t n = (int64_t)a.items * a.P;
+  hipLaunchKernelGGL(k_heat_raw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+}
+
+__global__ void k_heat_init(HeatArgs a) {
+  const int item = blockIdx.x;
+  uint32_t* st = a.stats + (int64_t)item * kHeatStatsWords;
+  for (int i = threadIdx.x; i < kHeatStatsWords; i += blockDim.x) st[i] = (i == 0) ? 0x7F7FFFFFu : 0u;
+}
+
+// min over positive y and max y of the context image (positive floats order like their bit patterns)
+__global__ __launch_bounds__(256) void k_heat_range(HeatArgs a) {
+  const int item = blockIdx.y;
+  const float* y = a.ctx + (int64_t)item * a.P;
+  uint32_t mn = 0x7F7FFFFFu, mx = 0u;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.P; i += gridDim.x * 256) {
+    const float v = y[i];
+    if (v > 0.0f) { mn = min(mn, __float_as_uint(v)); mx = max(mx, __float_as_uint(v)); }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = min(mn, (uint32_t)__shfl_down((int)mn, off, 64));
+    mx = max(mx, (uint32_t)__shfl_down((int)mx, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    uint32_t* st = a.stats + (int64_t)item * kHeatStatsWords;
+    atomicMin(&st[0], mn);
+    atomicMax(&st[1], mx);
+  }
+}
+
+__device__ __forceinline__ float log_lum(float y, float clampval) { return logf(fmaxf(y, clampval)); }
+
+__global__ __launch_bounds__(256) void k_heat_hist(HeatArgs a) {
+  __shared__ uint32_t s_h[1024];
+  const int item = blockIdx.y;
+  uint32_t* st = a.stats + (int64_t)item * kHeatStatsWords;
+  const float clampval = __uint_as_float(st[0]);
+  const float bmin = logf(clampval), bmax = logf(fmaxf(__uint_as_float(st[1]), clampval));
+  for (int i = threadIdx.x; i < 1024; i += 256) s_h[i] = 0;
+  __syncthreads();
+  const float* y = a.ctx + (int64_t)item * a.P;
+  const float range = bmax - bmin;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.P; i += gridDim.x * 256) {
+    const float b = log_lum(y[i], clampval);
+    int pos = (int)((b - bmin) / range * 1024.0f);   // torch.histc bin rule
+    pos = min(max(pos, 0), 1023);
+    atomicAdd(&s_h[pos], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 1024; i += 256)
+    if (s_h[i]) atomicAdd(&st[4 + i], s_h[i]);
+}
+
+// tone curve v = cumsum(p^(1/3) / sum p^(1/3)) * 0.6 + 0.2   (visualize_diff_map.py:33-43)
+__global__ __launch_bounds__(256) void k_heat_curve(HeatArgs a) {
+  __shared__ float s_p[1024];
+  __shared__ float s_tmp[4];
+  const int item = blockIdx.x, t = threadIdx.x;
+  const uint32_t* st = a.stats + (int64_t)item * kHeatStatsWords;
+  float* cv = a.curve + (int64_t)item * kHeatCurveWords;
+  const float clampval = __uint_as_float(st[0]);
+  const float bmin = logf(clampval), bmax = logf(fmaxf(__uint_as_float(st[1]), clampval));
+  float part = 0.0f;
+  for (int i = t; i < 1024; i += 256) {
+    const float p = (float)st[4 + i] / (float)a.P;
+    const float c = powf(p, 1.0f / 3.0f);
+    s_p[i] = c;
+    part += c;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+  if ((t & 63) == 0) s_tmp[t >> 6] = part;
+  __syncthreads();
+  if (t == 0) {
+    const float tot = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+    float run = 0.0f;
+    for (int i = 0; i < 1024; ++i) {
+      run += s_p[i] / tot;
+      cv[i] = run * 0.6f + 0.2f;
+    }
+    cv[1024] = bmin;
+    cv[1025] = bmax;
+    cv[1026] = (bmax - bmin < 0.6f) ? 0.0f : 1.0f;
+  }
+}
+
+__device__ __forceinline__ float scale_node(int i, float bmin, float bmax, float step) {
+  // torch.linspace(bmin, bmax, 1024): lower half from the start, upper half from the end
+  return (i < 512) ? bmin + step * (float)i : bmax - step * (float)(1023 - i);
+}
+
+__global__ __launch_bounds__(256) void k_heat_colour(HeatArgs a) {
+  const int item = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.P) return;
+  const uint32_t* st = a.stats + (int64_t)item * kHeatStatsWords;
+  const float* cv = a.curve + (int64_t)item * kHeatCurveWords;
+  const float clampval = __uint_as_float(st[0]);
+  const float bmin = cv[1024], bmax = cv[1025];
+  const float b = log_lum(a.ctx[(int64_t)item * a.P + i], clampval);
+  float tmo;
+  if (cv[1026] == 0.0f) {
+    tmo = (b - bmin) / (bmax - bmin + 1e-3f) * 0.6f + 0.2f;               // visualize_diff_map.py:28-31
+  } else {
+    const float step = (bmax - bmin) / 1023.0f;
+    int hi = (int)ceilf((b - bmin) / step);
+    hi = min(max(hi, 0), 1023);
+    while (hi > 0 && scale_node(hi - 1, bmin, bmax, step) >= b) --hi;     // bucketize: smallest node >= b
+    while (hi < 1023 && scale_node(hi, bmin, bmax, step) < b) ++hi;
+    const int lo = max(hi - 1, 0);
+    const float xl = scale_node(lo, bmin, bmax, step), xh = scale_node(hi, bmin, bmax, step);
+    float fr = (b - xl) / (xh - xl + 0.000001f);
+    if (hi == lo || fr < 0.0f) fr = 0.0f;
+    tmo = cv[lo] * (1.0f - fr) + cv[hi] * fr;
+  }
+  const float d = fminf(fmaxf(heat_value(a.recon[(int64_t)item * a.P + i], a.jod_a, a.jod_exp), 0.0f), 1.0f);
+  int hi = a.n_nodes;
+  for (int k = a.n_nodes - 1; k >= 0; --k)
+    if (a.cin[k] >= d) hi = k;
+  hi = min(hi, a.n_nodes - 1);
+  const int lo = max(hi - 1, 0);
+  float fr = (d - a.cin[lo]) / (a.cin[hi] - a.cin[lo] + 0.000001f);
+  if (hi == lo || fr < 0.0f) fr = 0.0f;
+  __half* out = reinterpret_cast<__half*>(a.out);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float col = a.cch[lo * 3 + c] * (1.0f - fr) + a.cch[hi * 3 + c] * fr;
+    const float c16 = __half2float(__float2half(col));                     // colour map is stored as fp16 first (:96-98)
+    out[((int64_t)c * a.items + item) * a.P + i] = __float2half(fminf(fmaxf(c16 * tmo, 0.0f), 1.0f));
+  }
+}
+
+void launch_heat_colour(const HeatArgs& a, hipStream_t s) {
+  const int gx = min((a.P + 255) / 256, 1024);
+  hipLaunchKernelGGL(k_heat_init, dim3(a.items), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_heat_range, dim3(gx, a.items), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_heat_hist, dim3(gx, a.items), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_heat_curve, dim3(a.items), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_heat_colour, dim3((a.P + 255) / 256, a.items), dim3(256), 0, s, a);
+}
+
+}  // namespace cvvdp

@@ -1,0 +1,130 @@
+// Internal launch interface between core.cpp (planning) and the gfx950 kernels.
+// Argument structs are passed by value as kernel arguments (they live in SGPRs / the kernarg
+// segment, so per-band constants cost no LDS and no vector loads).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cvvdp_hip.h"
+
+namespace cvvdp {
+
+constexpr float kEps = 0.00001f;  // safe_pow epsilon, cvvdp_metric.py:83
+
+// ---------------------------------------------------------------- photometry + DKL (K0)
+struct PhotoArgs {
+  const void* src[2];     // test, ref
+  int64_t sb[2], sc[2], sf[2], sh[2], sw[2];  // element strides
+  int32_t dtype, channels; // input sample type; 1 or 3 colour channels
+  int32_t H, W, batch, n_frames;
+  int32_t eotf;
+  float Y_peak, Y_black, Y_refl, exposure, gamma, scale;  // scale = fp32(Y_peak - Y_black)
+  float lin_lo;            // max(0.005, Y_black) for the linear EOTF
+  float hlg_c;             // 0.5 - a*ln(4a)
+  float m[9];
+  float* dst;              // destination base
+  int64_t d_side, d_ch, d_slot, d_b;  // element strides of the destination
+  int32_t first_slot, n_slots;        // slot = (first_slot + f) % n_slots
+};
+void launch_photometry(const PhotoArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- temporal FIR (K1)
+struct FirArgs {
+  const float* ring;       // [side][ch][slot][b][P]
+  int64_t r_side, r_ch, r_slot, r_b;
+  float* out;              // level-0 planes [plane][item][P]
+  int64_t o_plane;         // items_cap * P
+  int32_t P, batch, n_frames, fl;
+  float taps[4 * CVVDP_MAX_FILTER_LEN];  // flipped: taps[c][k] multiplies window position k
+  int16_t slots[CVVDP_MAX_WINDOW];
+};
+void launch_fir(const FirArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- gaussian pyramid reduce (K2)
+struct ReduceArgs {
+  const float* in;   // [planes*items][H*W]
+  float* out;        // [planes*items][Ho*Wo]
+  int32_t H, W, Ho, Wo, n_img;   // n_img = images actually processed per plane
+  int32_t img_cap;               // images allocated per plane (plane stride = img_cap * size)
+  int32_t n_planes;
+  float k[5];
+};
+void launch_reduce(const ReduceArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- fused band kernel (K3..K7)
+struct BandArgs {
+  const float* g;    // level l   planes [2*nch][items_cap][H*W]
+  const float* gc;   // level l+1 planes [2*nch][items_cap][Hc*Wc]
+  int32_t H, W, Hc, Wc;
+  int32_t items, items_cap, nch;
+  int32_t seg_h, n_seg, n_strip;
+  float band_mul;
+  float lut[4 * CVVDP_CSF_NODES];
+  float logL_first, logL_last;
+  float sens_mul;
+  float ch_gain[4];
+  float mask_c10, mask_p, eps_p;
+  float q[4], eps_q[4];
+  float xw[16];
+  float dmax;
+  float blur[13];
+  float kx[3];       // expand taps: 2*K[0], 2*K[2] (even), 2*K[1] (odd)
+  float* partial;    // [items][n_strip*n_seg][4]
+  float* dchr;       // heat band [items_cap][H*W] or null
+  float hw[4];       // heat channel weights
+  float beta_tch, eps_btch, eps_inv_btch;
+  float* ddump;      // debug [4][items_cap][H*W] or null
+};
+void launch_band(const BandArgs& a, bool blur, hipStream_t s);
+
+struct BaseArgs {
+  const float* g;    // baseband planes [2*nch][items_cap][P]
+  int32_t H, W, items, items_cap, nch;
+  float lut[4 * CVVDP_CSF_NODES];
+  float logL_first, logL_last, sens_mul;
+  float* q_out;      // Q_per_ch base
+  int32_t q_frames, q_levels, q_frame_offset, level, batch;
+  float* dchr; float hw[4]; float beta_tch, eps_btch, eps_inv_btch;
+  float* ddump;
+};
+void launch_baseband(const BaseArgs& a, hipStream_t s);
+
+struct FinalizeArgs {
+  const float* partial;  // [items][nblk][4]
+  int32_t items, nblk, nch, P;
+  float* q_out; int32_t q_frames, q_levels, q_frame_offset, level, batch;
+};
+void launch_finalize(const FinalizeArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- pooling + JOD (K8)
+struct PoolArgs {
+  const float* q; int32_t B, C, F, L;
+  float ch_w[4], bb_w[4];
+  float beta_sch, beta_tch, beta_t, jod_a, jod_exp, image_int;
+  float* jod;
+};
+void launch_pool(const PoolArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- heat map (K9, K10)
+struct ExpandAddArgs {
+  float* fine; const float* coarse; int32_t H, W, Hc, Wc, n_img; float kx[3];
+};
+void launch_expand_add(const ExpandAddArgs& a, hipStream_t s);
+
+struct HeatArgs {
+  const float* recon;     // [items][P] reconstructed difference pyramid (level-0 heat band)
+  const float* ctx;       // context image: test Y-sustained level-0 plane [items][P] (cvvdp_metric.py:400)
+  int32_t P, items, mode;
+  float jod_a, jod_exp;
+  uint32_t* stats;        // per item kHeatStatsWords words: [0] min positive y (bits), [1] max y (bits), [4..) histogram
+  float* curve;           // per item 1024 tone-curve values + [1024]=b_min, [1025]=b_max, [1026]=flag(1: histogram curve)
+  void* out;              // fp16 [ch][items][P]
+  int32_t n_nodes;        // colour map nodes (5 threshold, 3 supra-threshold)
+  float cin[5];           // node positions
+  float cch[15];          // node colours / luminance, [node][rgb]  (visualize_diff_map.py:93-94)
+};
+void launch_heat_raw(const HeatArgs& a, hipStream_t s);
+void launch_heat_colour(const HeatArgs& a, hipStream_t s);
+constexpr int kHeatStatsWords = 4 + 1024;
+constexpr int kHeatCurveWords = 1024 + 4;
+
+}  // namespace cvvdp

@@ -1,0 +1,462 @@
+"""ColorVideoVDP metric class for MI355X: host-side mirror of pycvvdp/cvvdp_metric.py `class cvvdp`.
+
+Same constructor, methods, argument meaning, outputs and error behaviour as the reference class
+(cvvdp_metric.py:108-441, 1094-1218), so `from colorvideovdp_amd import cvvdp` is a drop-in for
+`from pycvvdp import cvvdp` on this path.  All per-pixel work is done by the hand-written gfx950
+kernels behind the C ABI in include/cvvdp_hip.h; this file only plans blocks of frames, moves
+pointers and mirrors the reference's host-side bookkeeping (temporal padding, stats dict, distogram).
+
+Differences that are deliberate:
+  * GPU only.  There is no CPU path and no fallback: without the HIP library or a GPU the class raises.
+  * inference only.  `loss()` returns 10-JOD without autograd (the reference is differentiable).
+  * frames per block are chosen for occupancy / memory, never change results beyond fp32 rounding, and
+    heat-map tone-mapping statistics are always per frame (the reference's CPU behaviour; on CUDA the
+    reference lets them depend on the block size).
+  * optional frame-range sharding over torch.distributed (RCCL): see `set_frame_sharding`.
+"""
+import ctypes
+import json
+import logging
+import math
+
+import numpy as np
+import torch
+
+from . import _capi
+from . import host_setup as hs
+from .config import load_config
+from .display_model import vvdp_display_geometry, vvdp_display_photo_eotf, vvdp_display_photometry
+from .sharding import all_gather_frames, plan_frame_shard
+from .video_source import video_source_array
+from .vq_metric import register_metric, vq_exception, vq_metric
+
+f32 = np.float32
+
+
+class cvvdp(vq_metric):
+    def __init__(self, display_name="standard_4k", display_photometry=None, display_geometry=None, config_paths=[],
+                 heatmap=None, quiet=False, device=None, temp_padding="replicate", use_checkpoints=False, dump_channels=None,
+                 gpu_mem=None, block_frames=None):
+        self.quiet = quiet
+        self.heatmap = heatmap
+        self.temp_padding = temp_padding
+        self.use_checkpoints = use_checkpoints
+        self.gpu_mem = gpu_mem
+        self.block_frames = block_frames
+        self.training_mode = False
+        assert heatmap in ["threshold", "supra-threshold", "raw", "none", None], "Unknown heatmap type"
+        self.do_heatmap = (self.heatmap is not None) and (self.heatmap != "none")
+        if dump_channels:
+            raise vq_exception("dump_channels is a debugging aid of the reference implementation and is not supported")
+        self.dump_channels = None
+        _capi.lib()  # fail loudly (ImportError) if the HIP library is missing
+        if device is None:
+            self.device = torch.device("cuda")
+        else:
+            self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("colorvideovdp_amd runs on an MI355X only: device must be a CUDA/HIP device; there is no CPU path")
+        self._handle = ctypes.c_void_p()
+        self._ws = None
+        self._shard = None
+        self.debug_dump = False
+        self.set_display_model(display_name, display_photometry=display_photometry, display_geometry=display_geometry,
+                               config_paths=config_paths)
+        self.load_config(config_paths)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None and self._handle.value:
+                _capi.lib().cvvdp_destroy(self._handle)
+                self._handle = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    def train(self, do_training=True):
+        self.training_mode = do_training
+
+    # ------------------------------------------------------------------ configuration
+    def load_config(self, config_paths):
+        """cvvdp_metric.py:146-229.  Only the shipped model family is implemented by the kernels."""
+        p = load_config("cvvdp_parameters.json", config_paths)
+        self.parameters = p
+        if p["masking_model"] != "mult-mutual" or p["contrast"] != "weber_g1" or p["dclamp_type"] != "soft" \
+                or p["csf"] != "weber_fixed_size" or p["xchannel_masking"] != "on" or "block_channels" in p \
+                or p.get("temp_filter", "default") != "default" or "ch_chrom_w" not in p or "mask_q" not in p:
+            raise RuntimeError("Only the ColorVideoVDP v0.5.x base model is implemented by the HIP kernels "
+                               "(masking 'mult-mutual', contrast 'weber_g1', soft clamp, csf 'weber_fixed_size', cross-channel masking on)")
+        if p["beta"] != 2:
+            raise RuntimeError("The fused band kernel implements the spatial p-norm for beta=2 only")
+        self.version = p["version"]
+        self.pu_dilate = p["pu_dilate"]
+        if self.pu_dilate not in (0, 3):
+            raise RuntimeError("pu_dilate must be 0 or 3")
+        self.csf_table = hs.CsfTable(load_config("csf_lut_weber_fixed_size.json", config_paths))
+        self.jod_a, self.jod_exp = f32(p["jod_a"]), f32(p["jod_exp"])
+        self.baseband_weight = np.asarray(p["baseband_weight"], dtype=f32)
+        self.ch_w = np.asarray([1.0, p["ch_chrom_w"], p["ch_chrom_w"], p["ch_trans_w"]], dtype=f32)
+        self._make_handle()
+
+    def _make_handle(self):
+        if not hasattr(self, "parameters") or not hasattr(self, "display_photometry"):
+            return
+        p, dm = self.parameters, self.display_photometry
+        if not isinstance(dm, vvdp_display_photo_eotf):
+            raise RuntimeError("display_photometry must be a vvdp_display_photo_eotf")
+        P = _capi.Params()
+        P.eotf, P.gamma = dm.eotf_params()
+        Yb, Yr = dm.get_black_level()
+        P.Y_peak, P.Y_black, P.Y_refl, P.exposure = dm.Y_peak, Yb, Yr, dm.exposure
+        P.rgb2dkl[:] = dm.rgb2dkl_fp32().reshape(-1).tolist()
+        P.mask_p = p["mask_p"]
+        P.mask_c10 = float(np.power(f32(10.0), f32(p["mask_c"])))
+        P.mask_q[:] = p["mask_q"]
+        P.xcm[:] = np.power(f32(2.0), np.asarray(p["xcm_weights"], dtype=f32)).tolist()
+        P.ch_gain[:] = [1.0, 1.45, 1.0, 1.0]
+        P.d_max10 = float(np.power(f32(10.0), f32(p["d_max"])))
+        P.sens_mul = float(np.power(f32(10.0), f32(p["sensitivity_correction"]) / f32(20.0)))
+        P.blur_radius = int(self.pu_dilate * 2)
+        P.blur_taps[:] = hs.gaussian_taps(13, 3.0).tolist()
+        P.beta, P.beta_t, P.beta_tch, P.beta_sch = p["beta"], p["beta_t"], p["beta_tch"], p["beta_sch"]
+        P.jod_a, P.jod_exp, P.image_int = p["jod_a"], p["jod_exp"], p["image_int"]
+        P.ch_w[:] = self.ch_w.tolist()
+        P.baseband_weight[:] = p["baseband_weight"]
+        P.csf_logL_first, P.csf_logL_last = float(self.csf_table.log_L[0]), float(self.csf_table.log_L[-1])
+        lib = _capi.lib()
+        if self._handle.value:
+            lib.cvvdp_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+        rc = lib.cvvdp_create(ctypes.byref(P), ctypes.byref(self._handle))
+        if rc != 0:
+            raise RuntimeError(f"cvvdp_create failed ({rc})")
+        self._params = P
+
+    def set_display_model(self, display_name="standard_4k", display_photometry=None, display_geometry=None, config_paths=[]):
+        """cvvdp_metric.py:246-264."""
+        if display_photometry is None:
+            self.display_photometry = vvdp_display_photometry.load(display_name, config_paths)
+            self.display_name = display_name
+        else:
+            self.display_photometry = display_photometry
+            self.display_name = getattr(display_photometry, "short_name", "unspecified")
+        if display_geometry is None:
+            self.display_geometry = vvdp_display_geometry.load(display_name, config_paths)
+        else:
+            self.display_geometry = display_geometry
+        self.pix_per_deg = self.display_geometry.get_ppd()
+        self._make_handle()
+
+    def set_frame_sharding(self, group="world"):
+        """Score only this rank's frame range (plus a temporal halo) and combine Q_per_ch over the
+        process group with one RCCL all-gather.  `group=None` turns sharding off.  Frame features depend only
+        on the frame and its filter_len-1 predecessors (cvvdp_metric.py:554-560), so the result equals the
+        single-GPU one up to fp32 rounding of nothing at all: the per-frame values are bit-identical."""
+        self._shard = group
+
+    # ------------------------------------------------------------------ public API
+    def predict(self, test_cont, reference_cont, dim_order="BCFHW", frames_per_second=0):
+        vs = video_source_array(test_cont, reference_cont, frames_per_second, dim_order=dim_order,
+                                display_photometry=self.display_photometry)
+        return self.predict_video_source(vs)
+
+    def loss(self, test_cont, reference_cont, dim_order="BCFHW", frames_per_second=0):
+        for a in (test_cont, reference_cont):
+            if torch.is_tensor(a) and a.requires_grad:
+                raise vq_exception("colorvideovdp_amd is inference-only: loss() does not propagate gradients")
+        Q_jod, _ = self.predict(test_cont, reference_cont, dim_order=dim_order, frames_per_second=frames_per_second)
+        return 10.0 - Q_jod
+
+    def predict_video_source(self, vid_source):
+        """cvvdp_metric.py:304-441."""
+        height, width, N_frames = vid_source.get_video_size()
+        batch_sz = vid_source.get_batch_size()
+        if batch_sz > 1 and self.do_heatmap:
+            raise vq_exception("Heatmaps not supported when batches are used")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device available: colorvideovdp_amd has no CPU path")
+        is_image = N_frames == 1
+        first, count = 0, N_frames
+        group = None
+        if self._shard is not None and not is_image and torch.distributed.is_available() and torch.distributed.is_initialized():
+            group = None if self._shard == "world" else self._shard
+            rank, world = torch.distributed.get_rank(group), torch.distributed.get_world_size(group)
+            first, count = plan_frame_shard(N_frames, rank, world)
+        Q_local, heatmap, rho_band = self._score_range(vid_source, first, count)
+        if group is not None or (self._shard is not None and count != N_frames):
+            Q_per_ch = all_gather_frames(Q_local, N_frames, group)
+        else:
+            Q_per_ch = Q_local
+        Q_jod = self.do_pooling_and_jods(Q_per_ch)
+        stats = {}
+        stats["Q_per_ch"] = Q_per_ch.detach().cpu().numpy()
+        stats["rho_band"] = rho_band
+        stats["frames_per_second"] = vid_source.get_frames_per_second()
+        stats["width"] = width
+        stats["height"] = height
+        stats["N_frames"] = N_frames
+        if self.do_heatmap:
+            stats["heatmap"] = heatmap
+            if count != N_frames:
+                stats["heatmap_frame_range"] = (first, first + count)
+        return (Q_jod.squeeze(), stats)
+
+    # ------------------------------------------------------------------ block planning
+    def _pick_block_frames(self, pix, batch, n_frames, fl, nch):
+        if self.block_frames is not None:
+            nb = int(self.block_frames)
+        else:
+            free, _total = torch.cuda.mem_get_info(self.device)
+            budget = free * 0.55
+            if self.gpu_mem is not None:
+                budget = min(budget, self.gpu_mem * 1e9)
+            per_frame = pix * batch * (2 * nch * 4 * 1.34 + 24) + (pix * 16 if self.do_heatmap else 0)
+            fixed = pix * batch * 24 * 2 * fl
+            nb = int((budget - fixed) // per_frame)
+            nb = min(nb, 64)
+        return max(1, min(nb, n_frames, _capi.MAX_WINDOW - fl + 1))
+
+    def _raw_block(self, vs, a, b):
+        """Frames [a,b) of test and reference as BCFHW tensors on the device + dtype code."""
+        if hasattr(vs, "get_raw_block"):
+            return vs.get_raw_block(a, b, self.device)
+        if isinstance(vs, video_source_array):
+            t, r, code = vs.raw_arrays()
+            t = t[:, :, a:b]
+            r = r[:, :, a:b]
+            if t.device != self.device:
+                t = t.to(self.device, non_blocking=True)
+            if r.device != self.device:
+                r = r.to(self.device, non_blocking=True)
+            return t, r, code
+        # generic video_source: frames arrive one by one, already in DKL (cvvdp_metric.py:503-504)
+        ts = [vs.get_test_frame(f, device=self.device, colorspace="DKLd65") for f in range(a, b)]
+        rs = [vs.get_reference_frame(f, device=self.device, colorspace="DKLd65") for f in range(a, b)]
+        t = torch.cat(ts, dim=2).to(torch.float32).contiguous()
+        r = torch.cat(rs, dim=2).to(torch.float32).contiguous()
+        return t, r, _capi.F32_DKL
+
+    def _put(self, t, r, code, first_slot, stream):
+        n = t.shape[2]
+        B = max(t.shape[0], r.shape[0])
+        st = list(t.stride())
+        sr = list(r.stride())
+        if t.shape[0] == 1 and B > 1:
+            st[0] = 0
+        if r.shape[0] == 1 and B > 1:
+            sr[0] = 0
+        rc = _capi.lib().cvvdp_put_frames(self._handle, t.data_ptr(), r.data_ptr(), code, (ctypes.c_int64 * 5)(*st),
+                                          (ctypes.c_int64 * 5)(*sr), first_slot, n, stream)
+        _capi.check(self._handle, rc, "cvvdp_put_frames")
+
+    def _score_range(self, vs, first, count):
+        """Q_per_ch [B, C, count, bands] (device tensor) of frames [first, first+count)."""
+        lib = _capi.lib()
+        height, width, N_total = vs.get_video_size()
+        B = vs.get_batch_size()
+        is_image = N_total == 1
+        nch = 3 if is_image else 4
+        pyr_height, freqs = hs.band_frequencies(width, height, self.pix_per_deg)
+        L = pyr_height + 1
+        rho_band = freqs.copy()
+        rho_band[L - 1] = 0.1  # cvvdp_metric.py:685-686
+        probe_t, probe_r, code = self._raw_block(vs, first, first + 1)
+        C = probe_t.shape[1]
+        clip = _capi.Clip()
+        clip.batch, clip.channels, clip.height, clip.width = B, C, height, width
+        clip.is_video, clip.n_frames, clip.n_levels = int(not is_image), count, L
+        clip.heatmap = _capi.HEATMAP[self.heatmap]
+        clip.debug_dump = int(self.debug_dump)
+        fl = 1
+        if not is_image:
+            F = hs.temporal_filters(vs.get_frames_per_second(), self.parameters["beta_tf"], self.parameters["sigma_tf"])
+            self.F = F
+            fl = F.shape[1]
+            if fl > _capi.MAX_FILTER_LEN:
+                raise vq_exception(f"frame rates above {(_capi.MAX_FILTER_LEN - 1) * 4} fps are not supported")
+            self.filter_len = fl
+            taps = np.zeros((4, _capi.MAX_FILTER_LEN), dtype=f32)
+            taps[:, :fl] = F
+            clip.taps[:] = taps.reshape(-1).tolist()
+            nb = self._pick_block_frames(height * width, B, count, fl, nch)
+            clip.filter_len, clip.block_frames = fl, nb
+            clip.ring_slots = fl - 1 + max(nb, fl)
+        rows = np.zeros((_capi.MAX_LEVELS, 4, _capi.CSF_NODES), dtype=f32)
+        for bb in range(L):
+            rows[bb] = self.csf_table.rows(rho_band[bb])
+        clip.csf_rows[:] = rows.reshape(-1).tolist()
+        _capi.check(self._handle, lib.cvvdp_configure(self._handle, ctypes.byref(clip)), "cvvdp_configure")
+        need = lib.cvvdp_workspace_bytes(self._handle)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        _capi.check(self._handle, lib.cvvdp_bind_workspace(self._handle, self._ws.data_ptr(), self._ws.numel()), "cvvdp_bind_workspace")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        heatmap = None
+        hm_ch = 1 if self.heatmap == "raw" else 3
+        if self.do_heatmap:
+            heatmap = torch.zeros([1, hm_ch, count, height, width], dtype=torch.float16, device="cpu")
+
+        def fetch_heatmap(ff, n):
+            buf = torch.empty((hm_ch, n, height, width), dtype=torch.float16, device=self.device)
+            _capi.check(self._handle, lib.cvvdp_get_heatmap(self._handle, n, buf.data_ptr(), stream), "cvvdp_get_heatmap")
+            heatmap[0, :, ff:ff + n] = buf.cpu()
+
+        if is_image:
+            self._put(probe_t, probe_r, code, 0, stream)
+            _capi.check(self._handle, lib.cvvdp_process_image(self._handle, stream), "cvvdp_process_image")
+            if self.do_heatmap:
+                fetch_heatmap(0, 1)
+        else:
+            nb, slots = clip.block_frames, clip.ring_slots
+
+            def src_index(j):  # temporal padding before frame 0, cvvdp_metric.py:506-529
+                if j >= 0:
+                    return j
+                return 0 if self.temp_padding == "replicate" else hs.symmetric_frame_index(j, N_total)
+
+            if self.temp_padding not in ("replicate", "symmetric"):
+                raise RuntimeError(f'Unknown padding method "{self.temp_padding}"')
+            loaded_hi = None
+            for ff in range(first, first + count, nb):
+                n = min(nb, first + count - ff)
+                window = [src_index(ff - (fl - 1) + k) for k in range(fl - 1 + n)]
+                lo, hi = min(window), max(window) + 1
+                if loaded_hi is None:
+                    loaded_hi = lo
+                if hi > loaded_hi:
+                    t, r, code = self._raw_block(vs, loaded_hi, hi)
+                    self._put(t, r, code, loaded_hi % slots, stream)
+                    loaded_hi = hi
+                win = (ctypes.c_int32 * len(window))(*[w % slots for w in window])
+                _capi.check(self._handle, lib.cvvdp_process_block(self._handle, win, n, ff - first, stream), "cvvdp_process_block")
+                if self.do_heatmap:
+                    fetch_heatmap(ff - first, n)
+        Q = torch.empty((B, nch, count, L), dtype=torch.float32, device=self.device)
+        _capi.check(self._handle, lib.cvvdp_get_q_per_ch(self._handle, Q.data_ptr(), stream), "cvvdp_get_q_per_ch")
+        return Q, heatmap, rho_band
+
+    # ------------------------------------------------------------------ pooling, info, outputs
+    def do_pooling_and_jods(self, Q_per_ch):
+        """cvvdp_metric.py:610-643 on the GPU.  Q_per_ch[batch, channel, frame, band] -> JOD[batch]."""
+        Q = torch.as_tensor(Q_per_ch, dtype=torch.float32, device=self.device).contiguous()
+        B, C, F, L = Q.shape
+        jod = torch.empty((B,), dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = _capi.lib().cvvdp_pool_jod(self._handle, Q.data_ptr(), B, C, F, L, jod.data_ptr(), stream)
+        _capi.check(self._handle, rc, "cvvdp_pool_jod")
+        return jod
+
+    def get_ch_weights(self, no_channels):
+        return self.ch_w[0:no_channels].reshape(1, -1, 1, 1)
+
+    def met2jod(self, Q):
+        """cvvdp_metric.py:646-658 (numpy, used by export_distogram)."""
+        Q = np.asarray(Q, dtype=f32)
+        Q_t = f32(0.1)
+        a_p = self.jod_a * np.power(Q_t, self.jod_exp - f32(1.0))
+        return np.where(Q <= Q_t, f32(10.0) - a_p * Q, f32(10.0) - self.jod_a * np.power(np.maximum(Q, Q_t), self.jod_exp)).astype(f32)
+
+    def full_name(self):
+        return "ColorVideoVDP"
+
+    def short_name(self):
+        return "cvvdp"
+
+    def quality_unit(self):
+        return "JOD"
+
+    def get_info_string(self):
+        if self.display_name.startswith("standard_"):
+            standard_str = self.display_name
+        else:
+            standard_str = f"custom-display: {self.display_name}"
+        L_black, L_refl = self.display_photometry.get_black_level()
+        return f'"{self.full_name()} v{self.version}, {self.pix_per_deg:.4g} [pix/deg], ' \
+               f"Lpeak={self.display_photometry.get_peak_luminance():.5g}, " \
+               f'Lblack={L_black:.4g}, Lrefl={L_refl:.4g} [cd/m^2], ({standard_str})"'
+
+    def write_features_to_json(self, stats, dest_fname):
+        """cvvdp_metric.py:1112-1127."""
+        Q_per_ch = stats["Q_per_ch"]
+        fmap = {}
+        for key, value in stats.items():
+            if key not in ["Q_per_ch", "heatmap"]:
+                fmap[key] = value.tolist() if isinstance(value, np.ndarray) else value
+        for cc in range(Q_per_ch.shape[1]):
+            for bb in range(Q_per_ch.shape[3]):
+                fmap[f"t{cc}_b{bb}"] = Q_per_ch[:, cc, :, bb].tolist()
+        with open(dest_fname, "w", encoding="utf-8") as f:
+            json.dump(fmap, f, ensure_ascii=False, indent=4)
+
+    def export_distogram(self, stats, fname, jod_max=None, base_size=6):
+        """cvvdp_metric.py:1158-1218 (host only, needs matplotlib)."""
+        Q_per_ch = np.array(stats["Q_per_ch"], dtype=f32)
+        if Q_per_ch.shape[0] != 1:
+            raise vq_exception("Exporting distograms in batch mode is not supported")
+        ch_no = Q_per_ch.shape[1]
+        is_image = Q_per_ch.shape[2] == 1
+        Q_per_ch[:, :, :, -1] *= self.baseband_weight[0:ch_no].reshape(-1, 1)
+        Q_per_ch *= self.get_ch_weights(ch_no) * ch_no
+        dmap = 10.0 - self.met2jod(Q_per_ch)
+        if jod_max is None:
+            jod_max = math.ceil(dmap.max())
+        dmap = dmap / jod_max
+        fps = stats["frames_per_second"]
+        frame_no = Q_per_ch.shape[2]
+        rho_band = stats["rho_band"]
+        band_labels = [f"{val:.2f}" for val in np.flip(rho_band)[::2]]
+        band_labels[0] = "BB"
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+            from matplotlib import ticker
+            from matplotlib.colors import Normalize
+        except ImportError:
+            raise RuntimeError("matplotlib is missing. Please install it before exporting distograms.")
+        fig, axs = plt.subplots(nrows=ch_no, figsize=(base_size * frame_no / 60 + 1, base_size))
+        ch_labels = ["A-sust", "RG", "YV", "A-trans"]
+        cmap = plt.colormaps["plasma"]
+        for kk in range(ch_no):
+            dmap_ch = np.flip(np.transpose(dmap[0, kk, :, :].clip(0.0, 1.0)), axis=0)
+            axs[kk].imshow(dmap_ch, cmap=cmap, aspect="auto")
+            axs[kk].set_ylabel(ch_labels[kk])
+            axs[kk].yaxis.set_major_locator(ticker.FixedLocator(range(0, len(band_labels) * 2, 2)))
+            axs[kk].yaxis.set_minor_locator(ticker.MultipleLocator(1.0))
+            axs[kk].set_yticklabels(band_labels)
+            if kk == (ch_no - 1) and not is_image:
+                axs[kk].xaxis.set_major_formatter(lambda x, pos: str(int(x / fps * 1000)))
+                axs[kk].set_xlabel("Time [ms]")
+                axs[kk].xaxis.set_minor_locator(ticker.MultipleLocator(1.0))
+            else:
+                axs[kk].set_xticks([])
+        if is_image:
+            plt.subplots_adjust(bottom=0.1, right=0.5, top=0.9)
+            cax = plt.axes([0.725, 0.1, 0.125, 0.8])
+        else:
+            plt.subplots_adjust(bottom=0.1, right=0.9, top=0.9)
+            cax = plt.axes([0.925, 0.1, 0.025, 0.8])
+        plt.colorbar(plt.cm.ScalarMappable(norm=Normalize(0, jod_max), cmap=cmap), cax=cax, cmap=cmap)
+        plt.savefig(fname, bbox_inches="tight")
+        plt.close(fig)
+
+    # ------------------------------------------------------------------ test / bench hooks
+    def debug_buffer(self, which, level=0):
+        """float32 view of an internal workspace buffer (tests only)."""
+        ptr, n = ctypes.c_void_p(), ctypes.c_size_t()
+        rc = _capi.lib().cvvdp_debug_buffer(self._handle, which, level, ctypes.byref(ptr), ctypes.byref(n))
+        _capi.check(self._handle, rc, "cvvdp_debug_buffer")
+        off = ptr.value - self._ws.data_ptr()
+        return self._ws[off:off + n.value * 4].view(torch.float32)
+
+    def profile(self, enable=True):
+        _capi.check(self._handle, _capi.lib().cvvdp_profile_enable(self._handle, int(enable)), "cvvdp_profile_enable")
+
+    def profile_read(self):
+        ms = (ctypes.c_double * _capi.PROF_N)()
+        cnt = (ctypes.c_int32 * _capi.PROF_N)()
+        _capi.check(self._handle, _capi.lib().cvvdp_profile_read(self._handle, ms, cnt), "cvvdp_profile_read")
+        return {name: (ms[i], cnt[i]) for i, name in enumerate(_capi.PROF_NAMES)}
+
+
+register_metric(cvvdp)

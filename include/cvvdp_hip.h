@@ -1,0 +1,165 @@
+/* cvvdp_hip.h -- C ABI of the MI355X (gfx950) ColorVideoVDP compute core.
+ *
+ * The reference (gfxdisp/ColorVideoVDP, pure Python/PyTorch) has no FFI; its extension point
+ * is the Python class `cvvdp` (pycvvdp/cvvdp_metric.py:108).  This header is the boundary a
+ * binding for that class talks to: every entry point replaces a span of reference code, cited
+ * next to it (paths relative to the reference root).  The Python mirror that consumes it is
+ * colorvideovdp_amd/cvvdp_metric.py through ctypes (colorvideovdp_amd/_capi.py); see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; all `dev` pointers are HIP device pointers (e.g. tensor.data_ptr()).
+ *   - every function returns 0 on success, a negative CVVDP_E_* code otherwise; nothing throws.
+ *     cvvdp_last_error() returns a human-readable message for the last failure on that handle.
+ *   - one handle per (process, GPU); a handle is not thread-safe.
+ *   - all device work is enqueued on the caller's hipStream_t (passed as void*); no entry point
+ *     synchronises the device.
+ *   - the core allocates no device memory: the caller provides one workspace buffer of
+ *     cvvdp_workspace_bytes() bytes (so torch's caching allocator stays the only allocator).
+ *   - "item" = one (frame-in-block, batch) pair; item index = frame * batch + b.
+ */
+#ifndef CVVDP_HIP_H
+#define CVVDP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVVDP_ABI_VERSION 1
+#define CVVDP_MAX_FILTER_LEN 65 /* 0.25 s at up to 256 fps, cvvdp_metric.py:1059 */
+#define CVVDP_MAX_LEVELS 16
+#define CVVDP_MAX_WINDOW 256    /* filter_len - 1 + frames per block */
+#define CVVDP_CSF_NODES 32
+
+enum {
+  CVVDP_OK = 0,
+  CVVDP_E_ARG = -1,      /* invalid argument */
+  CVVDP_E_STATE = -2,    /* call order violated (e.g. no workspace bound) */
+  CVVDP_E_HIP = -3,      /* a HIP runtime call or kernel launch failed */
+  CVVDP_E_UNSUPPORTED = -4
+};
+
+/* input sample formats, video_source.py:320-346 */
+enum { CVVDP_U8 = 0, CVVDP_U16 = 1, CVVDP_F16 = 2, CVVDP_F32 = 3, CVVDP_F32_DKL = 4 /* already DKL-d65, fp32 */ };
+/* EOTFs, display_model.py:333-365 */
+enum { CVVDP_EOTF_SRGB = 0, CVVDP_EOTF_PQ = 1, CVVDP_EOTF_HLG = 2, CVVDP_EOTF_LINEAR = 3, CVVDP_EOTF_GAMMA = 4 };
+/* heat-map modes, cvvdp_metric.py:117 */
+enum { CVVDP_HEATMAP_NONE = 0, CVVDP_HEATMAP_RAW = 1, CVVDP_HEATMAP_THRESHOLD = 2, CVVDP_HEATMAP_SUPRA = 3 };
+/* debug/inspection buffers inside the workspace (tests) */
+enum { CVVDP_BUF_RING = 0, CVVDP_BUF_GPYR = 1, CVVDP_BUF_DDUMP = 2, CVVDP_BUF_HEAT = 3, CVVDP_BUF_Q = 4 };
+
+/* Calibrated parameters + display photometry.  Host-side scalars of cvvdp_parameters.json as
+ * loaded by cvvdp.load_config (cvvdp_metric.py:146-229) and of vvdp_display_photo_eotf
+ * (display_model.py:301-376).  Derived constants (10^x, 2^x) are computed by the host mirror in
+ * fp32 exactly where the reference computes them in fp32. */
+typedef struct cvvdp_params {
+  /* display photometry, display_model.py:333-376 */
+  int32_t eotf;
+  float Y_peak, Y_black, Y_refl, exposure;
+  float gamma;        /* EOTF exponent for CVVDP_EOTF_GAMMA; system gamma for HLG */
+  float rgb2dkl[9];   /* row-major fp32 LMS2006_to_DKLd65 @ XYZ_to_LMS2006 @ rgb2xyz, display_model.py:256 */
+  /* masking model "mult-mutual", cvvdp_metric.py:835-856 */
+  float mask_p;
+  float mask_c10;     /* 10^mask_c */
+  float mask_q[4];
+  float xcm[16];      /* 2^xcm_weights reshaped [from][to], cvvdp_metric.py:758-760 */
+  float ch_gain[4];   /* [1, 1.45, 1, 1], cvvdp_metric.py:835 */
+  float d_max10;      /* 10^d_max, cvvdp_metric.py:949 */
+  float sens_mul;     /* 10^(sensitivity_correction/20), cvvdp_metric.py:709 */
+  int32_t blur_radius;/* int(pu_dilate*2) = 6; 0 disables phase uncertainty blur */
+  float blur_taps[13];/* torchvision GaussianBlur(13, 3) 1-D kernel */
+  /* pooling + JOD, cvvdp_metric.py:610-658 */
+  float beta, beta_t, beta_tch, beta_sch;
+  float jod_a, jod_exp, image_int;
+  float ch_w[4];           /* [1, ch_chrom_w, ch_chrom_w, ch_trans_w] */
+  float baseband_weight[4];
+  /* castleCSF luminance axis (uniform in log10), csf.py:13, interp.py:92-100 */
+  float csf_logL_first, csf_logL_last;
+} cvvdp_params;
+
+/* Per-clip configuration: geometry of the pyramid, temporal filters, CSF rows.
+ * Replaces the host-side set-up in cvvdp.predict_video_source (cvvdp_metric.py:304-363),
+ * lpyr_dec.__init__ (lpyr_dec.py:18-52), get_temporal_filters (cvvdp_metric.py:1057-1092) and the
+ * rho-interpolated CSF cache (csf.py:39-46). */
+typedef struct cvvdp_clip {
+  int32_t batch, channels;      /* B; C in {1,3} of the input arrays */
+  int32_t height, width;
+  int32_t is_video;             /* 0: image (3 channels, no temporal filter), 1: video (4 channels) */
+  int32_t n_frames;             /* frames this handle scores (capacity of Q_per_ch along F) */
+  int32_t n_levels;             /* pyramid band count (lpyr.get_band_count()) */
+  int32_t filter_len;           /* temporal filter length (video) */
+  int32_t block_frames;         /* max frames per process_block call */
+  int32_t ring_slots;           /* physical slots of the DKL ring (video) */
+  int32_t heatmap;              /* CVVDP_HEATMAP_* */
+  int32_t debug_dump;           /* 1: keep per-pixel D of every band in the workspace (tests) */
+  float taps[4 * CVVDP_MAX_FILTER_LEN];                             /* F[c][k], not flipped */
+  float csf_rows[CVVDP_MAX_LEVELS * 4 * CVVDP_CSF_NODES];           /* [band][ch][node] log10 S */
+} cvvdp_clip;
+
+typedef struct cvvdp_handle cvvdp_handle;
+
+int cvvdp_abi_version(void);
+/* sizeof(cvvdp_params), sizeof(cvvdp_clip) as compiled, so a binding can verify its struct layout. */
+void cvvdp_struct_sizes(int32_t* params_bytes, int32_t* clip_bytes);
+
+/* cvvdp.__init__/load_config/set_display_model device side (cvvdp_metric.py:109-264). */
+int cvvdp_create(const cvvdp_params* params, cvvdp_handle** out);
+void cvvdp_destroy(cvvdp_handle* h);
+const char* cvvdp_last_error(const cvvdp_handle* h);
+
+/* Start of predict_video_source for one clip or frame-range shard (cvvdp_metric.py:304-372). */
+int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip);
+size_t cvvdp_workspace_bytes(const cvvdp_handle* h);
+int cvvdp_bind_workspace(cvvdp_handle* h, void* dev_workspace, size_t bytes);
+
+/* Frame supply + display model: video_source_array._get_frame (video_source.py:320-346),
+ * vvdp_display_photo_eotf.forward (display_model.py:333-365), linear_2_target_colorspace 'DKLd65'
+ * (display_model.py:241-276).  Converts n_frames frames of test and reference (device arrays with
+ * element strides in B,C,F,H,W order; a broadcast batch has stride 0) and stores DKL planes in ring
+ * slots (first_slot + i) mod ring_slots (video) or directly as the 6 level-0 planes (image). */
+int cvvdp_put_frames(cvvdp_handle* h, const void* dev_test, const void* dev_ref, int32_t dtype,
+                     const int64_t strides_test[5], const int64_t strides_ref[5],
+                     int32_t first_slot, int32_t n_frames, void* stream);
+
+/* One block of frames: temporal FIR over the ring (cvvdp_metric.py:554-560), contrast pyramid
+ * (lpyr_dec.py:364-414), CSF (csf.py:28-51), masking + pooling per band (cvvdp_metric.py:691-734).
+ * window_slots[k] (host array, filter_len-1+n_frames entries) is the ring slot that holds sliding-
+ * window position k, i.e. frame (first - (filter_len-1) + k) after temporal padding; this is how the
+ * host mirror expresses replicate/symmetric padding (cvvdp_metric.py:506-529) without copying.
+ * Results land in Q_per_ch[:, :, q_frame_offset : q_frame_offset+n_frames, :]. */
+int cvvdp_process_block(cvvdp_handle* h, const int32_t* window_slots, int32_t n_frames,
+                        int32_t q_frame_offset, void* stream);
+/* Image variant (6 planes were written by cvvdp_put_frames), cvvdp_metric.py:462-465. */
+int cvvdp_process_image(cvvdp_handle* h, void* stream);
+
+/* stats['Q_per_ch'] as fp32 [B, C, F, bands] (cvvdp_metric.py:388-392,419). */
+int cvvdp_get_q_per_ch(cvvdp_handle* h, float* dev_out, void* stream);
+/* do_pooling_and_jods + met2jod (cvvdp_metric.py:610-658) on any [B,C,F,bands] device array. */
+int cvvdp_pool_jod(cvvdp_handle* h, const float* dev_q_per_ch, int32_t B, int32_t C, int32_t F,
+                   int32_t bands, float* dev_jod, void* stream);
+
+/* Heat map of the frames of the last processed block: lpyr_dec_2.reconstruct + met2jod
+ * (cvvdp_metric.py:724-744) and visualize_diff_map (visualize_diff_map.py:48-106, tone-mapped per
+ * frame = block of 1, the reference's CPU behaviour).  Output fp16 [channels(1|3), n_frames, H, W]. */
+int cvvdp_get_heatmap(cvvdp_handle* h, int32_t n_frames, void* dev_out_f16, void* stream);
+
+/* Test/inspection: device pointer + element count of an internal buffer (level where relevant). */
+int cvvdp_debug_buffer(cvvdp_handle* h, int32_t which, int32_t level, void** dev_ptr, size_t* n_floats);
+
+/* Profiling aid for bench.py: when enabled, the core brackets every kernel launch with hipEvents on
+ * the caller's stream, binned by kernel family.  cvvdp_profile_read synchronises on the recorded
+ * events, returns summed milliseconds and launch counts per family and resets the accumulators. */
+enum {
+  CVVDP_PROF_PHOTOMETRY = 0, CVVDP_PROF_FIR = 1, CVVDP_PROF_REDUCE = 2, CVVDP_PROF_BAND0 = 3,
+  CVVDP_PROF_BAND_REST = 4, CVVDP_PROF_HEATMAP = 5, CVVDP_PROF_N = 6
+};
+int cvvdp_profile_enable(cvvdp_handle* h, int32_t enable);
+int cvvdp_profile_read(cvvdp_handle* h, double total_ms[CVVDP_PROF_N], int32_t n_launches[CVVDP_PROF_N]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVVDP_HIP_H */

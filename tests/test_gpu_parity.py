@@ -1,0 +1,202 @@
+"""HIP path (through the C ABI) against the reference vectors and the CPU oracle.  Needs an MI355X.
+
+Tolerances (fp32 path, different summation order and libm than torch-CPU):
+  JOD        |d| <= 1e-3   (north-star bound; observed ~1e-5)
+  Q_per_ch   rtol 2e-4, atol 2e-6
+  heat map   fp16 output: <= 1e-3 of the pixels may differ by more than 2e-3, none by more than 2e-2
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cases, load_golden
+
+pytestmark = pytest.mark.gpu
+
+JOD_TOL = 1e-3
+
+
+def _metric(meta, **kw):
+    import colorvideovdp_amd as cv
+    if "custom_photometry" in meta:
+        ph = cv.vvdp_display_photo_eotf(**meta["custom_photometry"])
+        ge = cv.vvdp_display_geometry(**meta["custom_geometry"])
+        return cv.cvvdp(display_photometry=ph, display_geometry=ge, heatmap=meta["heatmap"], temp_padding=meta["temp_padding"], **kw)
+    return cv.cvvdp(display_name=meta["display"], heatmap=meta["heatmap"], temp_padding=meta["temp_padding"], **kw)
+
+
+def _inputs(g):
+    t, r = g["test"], g["ref"]
+    if t.dtype == np.float16:
+        return torch.tensor(t), torch.tensor(r)
+    return t, r
+
+
+def _check_heatmap(got, want):
+    got = got.numpy().astype(np.float32)
+    want = want.astype(np.float32)
+    assert got.shape == want.shape
+    d = np.abs(got - want)
+    assert (d > 2e-3).mean() < 1e-3, (d > 2e-3).mean()
+    assert d.max() < 2e-2, d.max()
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden(name):
+    g = load_golden(name)
+    meta = g["meta"]
+    m = _metric(meta)
+    t, r = _inputs(g)
+    jod, stats = m.predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+    assert jod.device.type == "cuda"
+    assert stats["Q_per_ch"].dtype == np.float32 and stats["Q_per_ch"].shape == g["Q_per_ch"].shape
+    np.testing.assert_allclose(stats["rho_band"], g["rho_band"], rtol=1e-12)
+    np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(jod.cpu().numpy(), g["jod"], atol=JOD_TOL)
+    assert m.get_info_string() == str(g["info"])
+    if "heatmap" in g:
+        assert stats["heatmap"].dtype == torch.float16 and stats["heatmap"].device.type == "cpu"
+        _check_heatmap(stats["heatmap"], g["heatmap"])
+
+
+@pytest.mark.parametrize("name", ["vid_u8_72x128x12_60_fhd", "vid_u16_67x121x20_30_4k_sym", "vid_u8_135x240x18_60_fhd_raw"])
+@pytest.mark.parametrize("block", [1, 5, 7])
+def test_block_size_invariance(name, block):
+    """ChangeLog v0.5.3: results must not depend on how many frames are processed at once."""
+    g = load_golden(name)
+    meta = g["meta"]
+    t, r = _inputs(g)
+    jod0, s0 = _metric(meta).predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+    jod1, s1 = _metric(meta, block_frames=block).predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+    np.testing.assert_array_equal(s0["Q_per_ch"], s1["Q_per_ch"])  # same kernels, same per-frame arithmetic
+    assert float(jod0) == float(jod1)
+    if "heatmap" in s0:
+        assert torch.equal(s0["heatmap"], s1["heatmap"])
+
+
+def test_intermediates_against_oracle():
+    """Ring (DKL), temporal channels, Gaussian pyramid and per-pixel D of every band vs the CPU oracle."""
+    from colorvideovdp_amd import _capi
+    from oracle import cvvdp_oracle as orc
+    g = load_golden("vid_u8_72x128x12_60_fhd")
+    meta = g["meta"]
+    m = _metric(meta)
+    m.debug_dump = True
+    t, r = _inputs(g)
+    m.predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+    o = orc.Oracle(display_name=meta["display"], keep=True)
+    o.predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+    d = o.dbg  # intermediates of the last frame
+    nfr, L = 12, len(d["gpyr"])
+    for l in range(L):
+        H, W = d["gpyr"][l].shape[-2:]
+        buf = m.debug_buffer(_capi.BUF_GPYR, l).cpu().numpy().reshape(8, -1, H, W)
+        np.testing.assert_allclose(buf[:, nfr - 1], d["gpyr"][l][0, :, 0].numpy(), rtol=2e-5, atol=2e-5)
+        dd = m.debug_buffer(_capi.BUF_DDUMP, l).cpu().numpy().reshape(4, -1, H, W)
+        np.testing.assert_allclose(dd[:, nfr - 1], d["D"][l][0, :, 0].numpy(), rtol=5e-4, atol=2e-5)
+
+
+def test_frame_shards_are_exact():
+    """Frame-range sharding with a real halo reproduces the unsharded per-frame features bit for bit."""
+    from colorvideovdp_amd.sharding import plan_frame_shard
+    from colorvideovdp_amd.video_source import video_source_array
+    g = load_golden("vid_u8_135x240x18_60_fhd_raw")
+    meta = g["meta"]
+    t, r = _inputs(g)
+    m = _metric(dict(meta, heatmap="none"))
+    _, s0 = m.predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+    vs = video_source_array(t, r, meta["fps"], dim_order=meta["dim_order"])
+    for world in (2, 3):
+        parts = []
+        for rank in range(world):
+            first, count = plan_frame_shard(18, rank, world)
+            q, _, _ = m._score_range(vs, first, count)
+            parts.append(q.cpu().numpy())
+        np.testing.assert_array_equal(np.concatenate(parts, axis=2), s0["Q_per_ch"])
+
+
+def test_device_resident_and_strided_inputs():
+    """Inputs already on the GPU, in a non-default dim order, are consumed in place."""
+    g = load_golden("vid_u8_72x128x12_60_fhd")
+    meta = g["meta"]
+    t, r = _inputs(g)
+    m = _metric(meta)
+    jod0, s0 = m.predict(t, r, dim_order="FHWC", frames_per_second=60)
+    tg = torch.tensor(t).cuda().permute(3, 0, 1, 2).contiguous()  # CFHW on device
+    rg = torch.tensor(r).cuda().permute(3, 0, 1, 2).contiguous()
+    jod1, s1 = m.predict(tg, rg, dim_order="CFHW", frames_per_second=60)
+    np.testing.assert_array_equal(s0["Q_per_ch"], s1["Q_per_ch"])
+    tf = (torch.tensor(t).float() / 255).cuda()
+    rf = (torch.tensor(r).float() / 255).cuda()
+    jod2, s2 = m.predict(tf, rf, dim_order="FHWC", frames_per_second=60)
+    np.testing.assert_allclose(s2["Q_per_ch"], s0["Q_per_ch"], rtol=1e-5, atol=1e-7)
+
+
+def test_custom_video_source_slow_path():
+    """A user video_source that returns DKL frames (the reference protocol) still works."""
+    import colorvideovdp_amd as cv
+    from oracle import cvvdp_oracle as orc
+    g = load_golden("vid_u8_36x64x9_60_sym_short")
+    meta = g["meta"]
+    t, r = _inputs(g)
+    disp = orc.Display("standard_fhd")
+    tt, rr = orc.to_bcfhw(t, "FHWC"), orc.to_bcfhw(r, "FHWC")
+
+    class Src(cv.video_source):
+        def get_video_size(self):
+            return (36, 64, 9)
+
+        def get_frames_per_second(self):
+            return 60
+
+        def get_test_frame(self, frame, device, colorspace):
+            assert colorspace == "DKLd65"
+            return disp.to_dkl(orc.fetch_frame(tt, frame)).to(device)
+
+        def get_reference_frame(self, frame, device, colorspace):
+            return disp.to_dkl(orc.fetch_frame(rr, frame)).to(device)
+
+    m = _metric(meta)
+    jod, stats = m.predict_video_source(Src())
+    np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(jod.cpu().numpy(), g["jod"], atol=JOD_TOL)
+
+
+def test_errors_match_reference_behaviour():
+    import colorvideovdp_amd as cv
+    m = cv.cvvdp(display_name="standard_fhd", heatmap="threshold")
+    x = np.zeros((2, 3, 1, 16, 16), dtype=np.float32)
+    with pytest.raises(cv.vq_exception):
+        m.predict(x, x, dim_order="BCFHW")  # heat map with a batch
+    m = cv.cvvdp(display_name="standard_fhd")
+    with pytest.raises(RuntimeError):
+        m.predict(np.zeros((3, 4, 16, 16), np.float32), np.zeros((3, 4, 16, 16), np.float32), dim_order="CFHW")  # video without fps
+    with pytest.raises(RuntimeError):
+        m.predict(np.zeros((16, 16, 2), np.float32), np.zeros((16, 16, 2), np.float32), dim_order="HWC")  # 2 channels
+    with pytest.raises(RuntimeError):
+        m.predict(np.zeros((16, 16, 3), np.float64), np.zeros((16, 16, 3), np.float64), dim_order="HWC")  # dtype
+    with pytest.raises(RuntimeError):
+        cv.cvvdp(display_name="no_such_display")
+
+
+def test_full_size_properties():
+    """BASELINE-size frames (1080p) through size-independent properties: identical clips score exactly
+    10 JOD with Q_per_ch == 0; a static clip has an exactly-zero transient channel after the filter has
+    settled on replicate padding; per-frame features do not depend on the block size."""
+    import colorvideovdp_amd as cv
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    ref = (torch.rand((1, 3, 1, 1080, 1920), generator=gen, device="cuda") * 255).to(torch.uint8).expand(1, 3, 20, 1080, 1920)
+    m = cv.cvvdp(display_name="standard_fhd")
+    jod, stats = m.predict(ref, ref, dim_order="BCFHW", frames_per_second=60)
+    assert float(jod) == 10.0
+    assert np.all(stats["Q_per_ch"] == 0)
+    noise = (torch.rand((1, 3, 1, 1080, 1920), generator=gen, device="cuda") * 12).to(torch.uint8)
+    test = torch.clamp(ref[:, :, :1].to(torch.int16) + noise.to(torch.int16) - 6, 0, 255).to(torch.uint8).expand(1, 3, 20, 1080, 1920)
+    jod, stats = m.predict(test, ref, dim_order="BCFHW", frames_per_second=60)
+    q = stats["Q_per_ch"]
+    assert 5.0 < float(jod) < 10.0
+    # static content: every frame sees the same window -> identical features in all frames
+    np.testing.assert_allclose(q[:, :, 1:], q[:, :, :1].repeat(19, axis=2), rtol=1e-5, atol=1e-7)
+    m2 = cv.cvvdp(display_name="standard_fhd", block_frames=3)
+    _, s2 = m2.predict(test, ref, dim_order="BCFHW", frames_per_second=60)
+    np.testing.assert_array_equal(s2["Q_per_ch"], q)

@@ -1,0 +1,136 @@
+"""CPU-only checks: the C-ABI library loads and exports everything include/cvvdp_hip.h declares,
+host-side set-up math against the reference vectors, frame-source reshaping, shard planning."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from colorvideovdp_amd import _capi
+    lib = _capi.lib()
+    hdr = open(os.path.join(ROOT, "include", "cvvdp_hip.h")).read()
+    declared = set(re.findall(r"\b(cvvdp_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"cvvdp_handle"}
+    assert declared, "no declarations found"
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+        assert name in _capi.SYMBOLS, f"{name} not bound in _capi.py"
+    assert set(_capi.SYMBOLS) == declared
+    assert lib.cvvdp_abi_version() == _capi.ABI_VERSION
+    p, c = ctypes.c_int32(), ctypes.c_int32()
+    lib.cvvdp_struct_sizes(ctypes.byref(p), ctypes.byref(c))
+    assert (p.value, c.value) == (ctypes.sizeof(_capi.Params), ctypes.sizeof(_capi.Clip))
+
+
+def test_abi_argument_validation_without_gpu():
+    from colorvideovdp_amd import _capi
+    lib = _capi.lib()
+    h = ctypes.c_void_p()
+    assert lib.cvvdp_create(None, ctypes.byref(h)) == -1
+    P = _capi.Params()
+    assert lib.cvvdp_create(ctypes.byref(P), ctypes.byref(h)) == 0
+    clip = _capi.Clip()
+    assert lib.cvvdp_configure(h, ctypes.byref(clip)) == -1  # empty geometry
+    assert b"geometry" in lib.cvvdp_last_error(h)
+    assert lib.cvvdp_workspace_bytes(h) == 0
+    clip.batch, clip.channels, clip.height, clip.width, clip.is_video, clip.n_frames, clip.n_levels = 1, 3, 1080, 1920, 1, 64, 8
+    clip.filter_len, clip.block_frames, clip.ring_slots = 17, 16, 33
+    assert lib.cvvdp_configure(h, ctypes.byref(clip)) == 0
+    need = lib.cvvdp_workspace_bytes(h)
+    P0 = 1080 * 1920
+    assert need > (6 * 33 + 8 * 16 * 1.33) * P0 * 4 and need < (6 * 33 + 8 * 16 * 1.35) * P0 * 4 + (1 << 22)
+    assert lib.cvvdp_process_block(h, None, 1, 0, None) == -2  # no workspace bound
+    lib.cvvdp_destroy(h)
+
+
+def test_host_setup_against_reference_vectors(setup_vectors):
+    import colorvideovdp_amd as cv
+    from colorvideovdp_amd import host_setup as hs
+    s = setup_vectors
+    m = cv.cvvdp(display_name="standard_4k")
+    for fps in (24, 25, 30, 50, 60, 120):
+        F = hs.temporal_filters(fps, m.parameters["beta_tf"], m.parameters["sigma_tf"])
+        np.testing.assert_allclose(F, s["taps_%d" % fps], atol=2e-7)
+    for i, rho in enumerate(s["csf_rhos"]):
+        np.testing.assert_allclose(m.csf_table.rows(rho), s["csf_rows"][i], rtol=2e-6, atol=2e-6)
+    np.testing.assert_array_equal(m.display_photometry.rgb2dkl_fp32(), s["dkl_standard_4k"])
+    np.testing.assert_allclose(np.array(m.display_photometry.get_black_level()), s["black_standard_4k"], rtol=1e-15)
+    hdr = cv.vvdp_display_photometry.load("standard_hdr_pq", [])
+    np.testing.assert_array_equal(hdr.rgb2dkl_fp32(), s["dkl_standard_hdr_pq"])
+    for row, disp in zip(s["band_sizes"], s["band_displays"]):
+        W, H, ppd, nb = int(row[0]), int(row[1]), row[2], int(row[3])
+        g = cv.vvdp_display_geometry.load(str(disp))
+        assert abs(g.get_ppd() - ppd) < 1e-9
+        h, fr = hs.band_frequencies(W, H, g.get_ppd())
+        assert h + 1 == nb
+        np.testing.assert_allclose(fr, row[4:4 + nb], rtol=1e-12)
+    assert m.get_info_string() == '"ColorVideoVDP v0.5.6, 75.4 [pix/deg], Lpeak=200, Lblack=0.2, Lrefl=0.3979 [cd/m^2], (standard_4k)"'
+    assert m.short_name() == "cvvdp" and m.quality_unit() == "JOD"
+    assert cv.vq_metric_dict["cvvdp"] is cv.cvvdp
+
+
+def test_symmetric_index_matches_reference_formula():
+    from colorvideovdp_amd import host_setup as hs
+    # frame -k maps to frame k; short clips ping-pong (cvvdp_metric.py:445-450)
+    assert [hs.symmetric_frame_index(-k, 30) for k in range(1, 6)] == [1, 2, 3, 4, 5]
+    assert [hs.symmetric_frame_index(-k, 4) for k in range(1, 9)] == [1, 2, 3, 2, 1, 0, 1, 2]
+
+
+def test_reshuffle_dims_and_array_source():
+    import colorvideovdp_amd as cv
+    x = torch.arange(2 * 3 * 4 * 5).reshape(4, 5, 3, 2)  # H W C F
+    y = cv.reshuffle_dims(x, "HWCF", "BCFHW")
+    assert tuple(y.shape) == (1, 3, 2, 4, 5)
+    assert y[0, 1, 1, 2, 3] == x[2, 3, 1, 1]
+    a = np.zeros((6, 8, 3), dtype=np.uint16)
+    a[1, 2, 0] = 65535
+    vs = cv.video_source_array(a, a, 0, dim_order="HWC")
+    t, r, code = vs.raw_arrays()
+    assert code == 1 and t.dtype == torch.int16 and tuple(t.shape) == (1, 3, 1, 6, 8) and t[0, 0, 0, 1, 2] == -1
+    assert vs.get_video_size() == (6, 8, 1) and vs.get_batch_size() == 1
+    with pytest.raises(RuntimeError):
+        cv.video_source_array(np.zeros((2, 6, 8, 3), np.uint8), np.zeros((2, 6, 8, 3), np.uint8), 0, dim_order="FHWC")
+    with pytest.raises(RuntimeError):
+        cv.video_source_array(np.zeros((6, 8, 3), np.uint8), np.zeros((6, 9, 3), np.uint8), 0, dim_order="HWC")
+
+
+def test_cpu_device_is_rejected_loudly():
+    import colorvideovdp_amd as cv
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        cv.cvvdp(device="cpu")
+    if not torch.cuda.is_available():
+        m = cv.cvvdp(display_name="standard_fhd")
+        x = np.zeros((16, 16, 3), np.uint8)
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            m.predict(x, x, dim_order="HWC")
+
+
+def test_config_paths_override(tmp_path):
+    import json
+    import colorvideovdp_amd as cv
+    models = {"my_display": {"name": "custom", "resolution": [1000, 500], "viewing_distance_meters": 1.0, "diagonal_size_inches": 20,
+                             "max_luminance": 321, "contrast": 100, "E_ambient": 0}}
+    f = tmp_path / "display_models_custom.json"
+    f.write_text(json.dumps(models))
+    m = cv.cvvdp(display_name="my_display", config_paths=[str(f)])
+    assert m.display_photometry.get_peak_luminance() == 321
+    assert "custom-display: my_display" in m.get_info_string()
+    with pytest.raises(RuntimeError):
+        cv.cvvdp(display_name="my_display")
+
+
+def test_shard_plan_covers_clip():
+    from colorvideovdp_amd.sharding import plan_frame_shard
+    for n in (1, 7, 64, 1024, 1023):
+        for world in (1, 2, 3, 8):
+            ranges = [plan_frame_shard(n, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and sum(c for _, c in ranges) == n
+            for (a, ca), (b, _) in zip(ranges, ranges[1:]):
+                assert a + ca == b
+            assert max(c for _, c in ranges) - min(c for _, c in ranges) <= 1

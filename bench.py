@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the ColorVideoVDP hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload 4k64|fhd64|4k256] [--dtype f32|u8]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full predict() of the workload clip pair (display model -> DKL -> temporal FIR ->
+contrast pyramid -> CSF -> masking -> pooling -> JOD) with the test/reference clips already resident in
+HBM.  With N GPUs the clip is N times longer and sharded by frame range (each rank: its frames + a
+16-frame real halo, one RCCL all-gather of Q_per_ch, pooling on every rank): weak scaling.
+
+Prints ONE JSON line (rank 0).  value = Mpixel/s of the whole job = W*H*frames_scored_by_all_ranks*K / t.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+WORKLOADS = {
+    # name: (W, H, frames per GPU, fps, display)
+    "4k64": (3840, 2160, 64, 60, "standard_4k"),      # BASELINE.json metric: "4K@60fps 64-frame clip"
+    "fhd64": (1920, 1080, 64, 60, "standard_fhd"),    # configs[1]
+    "4k256": (3840, 2160, 256, 60, "standard_4k"),    # configs[2]
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
+PATH_BYTES_PER_PIXEL = {"f32": 211.0, "u8": 193.0}   # SURVEY.md 8(d) whole-path algorithmic bytes
+BAND0_BYTES_PER_PIXEL = 40.0   # level-0 band kernel: reads g0 (8 planes x 4 B) + g1 (8 x 4 / 4)
+
+
+def synth_frame(f, H, W, device, seed_ref=1234, seed_noise=5678):
+    """One synthetic test/reference frame pair (uint8 [3,H,W]); depends only on the frame index, so a
+    rank can generate exactly its own frame range (SURVEY.md 8(d) recipe: moving plaid + smoothed hash
+    noise; test = ref + sigma 0.02 noise + 3 % flicker every 8th frame + 3-tap blur on the right half)."""
+    g = torch.Generator(device=device)
+    y = torch.arange(H, device=device, dtype=torch.float32).view(1, H, 1)
+    x = torch.arange(W, device=device, dtype=torch.float32).view(1, 1, W)
+    c = torch.arange(3, device=device, dtype=torch.float32).view(3, 1, 1)
+    g.manual_seed(seed_ref * 100003 + f)
+    u = torch.rand((1, 3, H, W), generator=g, device=device)
+    u = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(u, (1, 1, 1, 1), mode="replicate"), 3, stride=1)[0]
+    ref = 0.5 + 0.22 * torch.sin(2 * np.pi * (3 * x / W + f / 60.0)) * torch.cos(2 * np.pi * 2 * y / H + 0.7 * c) + 0.18 * (u - 0.5)
+    ref = torch.round(ref.clamp(0, 1) * 255) / 255
+    g.manual_seed(seed_noise * 100003 + f)
+    test = ref + 0.02 * torch.randn((3, H, W), generator=g, device=device)
+    if f % 8 == 0:
+        test = test * 0.97
+    half = W // 2
+    blur = (torch.nn.functional.pad(test[None], (1, 1, 0, 0), mode="replicate")[0].unfold(2, 3, 1).mean(-1))
+    test = torch.cat([test[:, :, :half], blur[:, :, half:]], dim=2)
+    return torch.round(test.clamp(0, 1) * 255).to(torch.uint8), torch.round(ref * 255).to(torch.uint8)
+
+
+class ResidentClip:
+    """video source whose frames [lo, hi) live in HBM; implements the raw-block fast path."""
+
+    def __init__(self, n_total, lo, hi, H, W, fps, dtype, device):
+        self.n_total, self.lo, self.hi, self.H, self.W, self.fps = n_total, lo, hi, H, W, fps
+        tdt = torch.float32 if dtype == "f32" else torch.uint8
+        self.code = 3 if dtype == "f32" else 0
+        self.test = torch.empty((1, 3, hi - lo, H, W), dtype=tdt, device=device)
+        self.ref = torch.empty((1, 3, hi - lo, H, W), dtype=tdt, device=device)
+        for f in range(lo, hi):
+            t, r = synth_frame(f, H, W, device)
+            if dtype == "f32":
+                t, r = t.float() / 255, r.float() / 255
+            self.test[0, :, f - lo] = t
+            self.ref[0, :, f - lo] = r
+
+    def get_video_size(self):
+        return (self.H, self.W, self.n_total)
+
+    def get_frames_per_second(self):
+        return self.fps
+
+    def get_batch_size(self):
+        return 1
+
+    def get_raw_block(self, a, b, device):
+        assert self.lo <= a and b <= self.hi, (a, b, self.lo, self.hi)
+        return self.test[:, :, a - self.lo:b - self.lo], self.ref[:, :, a - self.lo:b - self.lo], self.code
+
+
+def cpu_baseline(W, H, fps, display, n_frames):
+    """Oracle ('port' of the reference's torch-CPU path) on the first n_frames of the same synthetic clip."""
+    from oracle import cvvdp_oracle as orc
+    frames = [synth_frame(f, H, W, "cpu") for f in range(n_frames)]
+    t = torch.stack([a for a, _ in frames], dim=1).float().div(255)[None]   # [1,3,F,H,W]
+    r = torch.stack([b for _, b in frames], dim=1).float().div(255)[None]
+    o = orc.Oracle(display)
+    t0 = time.time()
+    with torch.no_grad():
+        jod, _ = o.predict(t, r, dim_order="BCFHW", frames_per_second=fps)
+    dt = time.time() - t0
+    return dict(value=W * H * n_frames / dt / 1e6, unit="Mpixel/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"first {n_frames} frames of the {W}x{H}@{fps} workload clip, oracle/cvvdp_oracle.py (torch CPU, block=1), {dt:.1f} s"), float(jod), t, r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="4k64", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="f32", choices=["f32", "u8"])
+    ap.add_argument("--block-frames", type=int, default=None)
+    ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=device)
+
+    import colorvideovdp_amd as cv
+    from colorvideovdp_amd.sharding import plan_frame_shard
+    W, H, per_gpu, fps, display = WORKLOADS[args.workload]
+    n_total = per_gpu * world
+    first, count = plan_frame_shard(n_total, rank, world)
+    m = cv.cvvdp(display_name=display, device=device, block_frames=args.block_frames)
+    fl = int(np.ceil(0.250 * fps / 2) * 2) + 1   # cvvdp_metric.py:1059
+    lo = max(0, first - (fl - 1))
+    clip = ResidentClip(n_total, lo, first + count, H, W, fps, args.dtype, device)
+    if world > 1:
+        m.set_frame_sharding("world")
+
+    def step():
+        return m.predict_video_source(clip)
+
+    for _ in range(args.warmup):
+        jod, stats = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    if not args.no_profile:
+        m.profile(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        jod, stats = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    prof = None if args.no_profile else m.profile_read()
+    m.profile(False)
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt)
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    pixels = W * H * n_total * args.steps
+    mpix = pixels / dt / 1e6
+    out = {
+        "metric": "Mpixels/s", "value": round(mpix, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{W}x{H} {fps}fps {per_gpu}-frame clip pair per GPU ({n_total} frames total), {display}, "
+                               f"{args.dtype} input resident in HBM, frame-range shards + 16-frame halo" if world > 1 else
+                               f"{W}x{H} {fps}fps {per_gpu}-frame clip pair, {display}, {args.dtype} input resident in HBM",
+                   "frames_per_gpu": per_gpu, "input_dtype": args.dtype, "block_frames": getattr(m, "last_block_frames", None)},
+        "jod": round(float(jod), 5),
+        "path_roofline": {"bytes_per_pixel": PATH_BYTES_PER_PIXEL[args.dtype],
+                          "achieved_GBs": round(PATH_BYTES_PER_PIXEL[args.dtype] * pixels / dt / 1e9 / world, 1),
+                          "frac_of_8TBs_per_gpu": round(PATH_BYTES_PER_PIXEL[args.dtype] * pixels / dt / 1e9 / world / HBM_PEAK_GBS, 4)},
+    }
+    if prof is not None:
+        ms, n = prof["band_level0"]
+        frames_per_launch = count * args.steps / max(n, 1)
+        avg_ms = ms / max(n, 1)
+        ach = BAND0_BYTES_PER_PIXEL * W * H * frames_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_band0.json")
+        if os.path.isfile(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("workload") == args.workload and tj.get("dtype") == args.dtype:
+                traffic = tj.get("hbm_bytes_per_launch")
+        out["roofline"] = {"bound": "hbm", "kernel": "k_band<4,true> level 0 (fused expand/contrast/CSF/masking/pooling)",
+                           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                           "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": n,
+                           "algorithmic_bytes_per_launch": BAND0_BYTES_PER_PIXEL * W * H * frames_per_launch}
+        tot = sum(v[0] for v in prof.values())
+        out["kernel_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in prof.items()}
+        out["kernel_ms_per_step"]["sum"] = round(tot / args.steps, 3)
+    if args.cpu_frames > 0 and world == 1:
+        cb, ojod, t, r = cpu_baseline(W, H, fps, display, args.cpu_frames)
+        out["cpu_baseline"] = cb
+        hjod, _ = cv.cvvdp(display_name=display, device=device).predict(t, r, dim_order="BCFHW", frames_per_second=fps)
+        out["jod_delta_vs_oracle"] = float(abs(float(hjod) - ojod))
+    print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -279,6 +279,7 @@ class cvvdp(vq_metric):
             clip.taps[:] = taps.reshape(-1).tolist()
             nb = self._pick_block_frames(height * width, B, count, fl, nch)
             clip.filter_len, clip.block_frames = fl, nb
+            self.last_block_frames = nb
             clip.ring_slots = fl - 1 + max(nb, fl)
         rows = np.zeros((_capi.MAX_LEVELS, 4, _capi.CSF_NODES), dtype=f32)
         for bb in range(L):

@@ -35,7 +35,7 @@ __device__ __forceinline__ float safe_powf(float x, float p, float eps_p) { retu
 
 // One step of the rotating 13-row window: store the new row in slot S, blur the 13 rows vertically.
 template <int S, int NCH>
-__device__ __forceinline__ void window_step(float (&win)[BW][4], const float (&h)[4], const float* bw, float (&v)[4]) {
+__device__ __forceinline__ void window_step(float (&win)[BW][NCH], const float (&h)[4], const float* bw, float (&v)[4]) {
 #pragma unroll
   for (int c = 0; c < NCH; ++c) win[S][c] = h[c];
 #pragma unroll
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(BT) void k_band(BandArgs a) {
   __shared__ float s_m[BLUR ? NCH : 1][BT];
   __shared__ float s_d[BLUR ? (R + 1) : 1][BLUR ? NCH : 1][BT];
   __shared__ float s_red[4][BT / 64];
+  __shared__ float s_lut[4 * CVVDP_CSF_NODES];  // log2-domain CSF rows: lut*log2(10) + log2(sens_mul)
 
   const int t = threadIdx.x;
   const int strip = blockIdx.x, seg = blockIdx.y, item = blockIdx.z;
@@ -80,13 +81,14 @@ __global__ __launch_bounds__(BT) void k_band(BandArgs a) {
   const int n_cx = cx_hi - cx_lo + 1;
 
   const float e0 = a.kx[0], e1 = a.kx[1], eo = a.kx[2];
-  const float dl = a.logL_last - a.logL_first;
+  const float ind_scale = (float)(CVVDP_CSF_NODES - 1) / (a.logL_last - a.logL_first);
+  if (t < 4 * CVVDP_CSF_NODES) s_lut[t] = a.lut[t] * kLog2_10 + fast_log2(a.sens_mul);
 
-  float win[BW][4];
+  float win[BW][NCH];
 #pragma unroll
   for (int j = 0; j < BW; ++j)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) win[j][c] = 0.0f;
+    for (int c = 0; c < NCH; ++c) win[j][c] = 0.0f;
   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
   for (int r = ys - R; r < ye + R; ++r) {
@@ -121,19 +123,20 @@ __global__ __launch_bounds__(BT) void k_band(BandArgs a) {
         else ex[p] = s_ve[p][ca] * e0 + s_ve[p][cb] * e1 + s_ve[p][cc] * e0;
       }
       const float Lt = fmaxf(ex[0], 0.01f), Lr = fmaxf(ex[1], 0.01f);     // lpyr_dec.py:394
-      const float logL = log10f(Lr);                                       // lpyr_dec.py:408, query = reference plane
-      float ind = (logL - a.logL_first) / dl * (float)(CVVDP_CSF_NODES - 1);  // interp.py:93
+      const float rLt = fast_rcp(Lt), rLr = fast_rcp(Lr);
+      const float logL = fast_log2(Lr) * kLog10_2;                        // lpyr_dec.py:408, query = reference plane
+      float ind = (logL - a.logL_first) * ind_scale;                       // interp.py:93
       ind = fminf(fmaxf(ind, 0.0f), (float)(CVVDP_CSF_NODES - 1));
       const int i0 = (int)ind;
       const float fr = ind - (float)i0;
       const int i1 = min(i0 + 1, CVVDP_CSF_NODES - 1);
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        const float ls = a.lut[c * CVVDP_CSF_NODES + i0] * (1.0f - fr) + a.lut[c * CVVDP_CSF_NODES + i1] * fr;
-        const float S = exp10f(ls) * a.sens_mul;                            // csf.py:49, cvvdp_metric.py:709
-        const float ct = fminf((gv[2 * c] - ex[2 * c]) / Lt, 1000.0f) * a.band_mul;       // lpyr_dec.py:402, :66
-        const float cr = fminf((gv[2 * c + 1] - ex[2 * c + 1]) / Lr, 1000.0f) * a.band_mul;
-        const float Tp = ct * S * a.ch_gain[c], Rp = cr * S * a.ch_gain[c]; // cvvdp_metric.py:836-837
+        const float l0 = s_lut[c * CVVDP_CSF_NODES + i0], l1 = s_lut[c * CVVDP_CSF_NODES + i1];
+        const float S = fast_exp2(l0 + (l1 - l0) * fr) * a.ch_gain[c];      // csf.py:49, cvvdp_metric.py:709,:836
+        const float ct = fminf((gv[2 * c] - ex[2 * c]) * rLt, 1000.0f) * a.band_mul;       // lpyr_dec.py:402, :66
+        const float cr = fminf((gv[2 * c + 1] - ex[2 * c + 1]) * rLr, 1000.0f) * a.band_mul;
+        const float Tp = ct * S, Rp = cr * S;
         m[c] = fminf(fabsf(Tp), fabsf(Rp));                                 // :845
         d[c] = fabsf(Tp - Rp);
       }
@@ -191,15 +194,15 @@ __global__ __launch_bounds__(BT) void k_band(BandArgs a) {
     if (interior && have) {
       float Mq[4];
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) Mq[c] = powf(fabsf(v[c] * a.mask_c10) + kEps, a.q[c]) - a.eps_q[c];
+      for (int c = 0; c < NCH; ++c) Mq[c] = fast_pow(fabsf(v[c] * a.mask_c10) + kEps, a.q[c]) - a.eps_q[c];
       float D[4];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         float M = 0.0f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) M += Mq[k] * a.xw[k * 4 + c];       // cvvdp_metric.py:758-760
-        const float Du = (powf(d[c] + kEps, a.mask_p) - a.eps_p) / (1.0f + M);
-        D[c] = a.dmax * Du / (a.dmax + Du);                               // soft clamp, :949-950
+        const float Du = (fast_pow(d[c] + kEps, a.mask_p) - a.eps_p) * fast_rcp(1.0f + M);
+        D[c] = a.dmax * Du * fast_rcp(a.dmax + Du);                       // soft clamp, :949-950
         const float de = D[c] + kEps;
         acc[c] += de * de - kEps * kEps;                                  // safe_pow(D, beta=2)
       }
@@ -211,8 +214,8 @@ __global__ __launch_bounds__(BT) void k_band(BandArgs a) {
       if (a.dchr) {  // cvvdp_metric.py:728-734, lpyr_dec.py:308-314
         float s = 0.0f;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) s += powf(D[c] * a.hw[c] + kEps, a.beta_tch) - a.eps_btch;
-        a.dchr[(int64_t)item * P + o] = (powf(s + kEps, 1.0f / a.beta_tch) - a.eps_inv_btch) / a.band_mul;
+        for (int c = 0; c < NCH; ++c) s += fast_pow(D[c] * a.hw[c] + kEps, a.beta_tch) - a.eps_btch;
+        a.dchr[(int64_t)item * P + o] = (fast_pow(s + kEps, 1.0f / a.beta_tch) - a.eps_inv_btch) / a.band_mul;
       }
     }
     // the next iteration's first __syncthreads orders the reuse of s_m / s_d; s_ve needs its own

@@ -68,7 +68,89 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
   }
 }
 
+// Fast path for W % 8 == 0 (all large levels): no LDS, no barriers.  A thread owns 4 adjacent output
+// columns and marches down a segment of output rows.  Per input row it loads 16+8 samples as aligned
+// float4 (coalesced: a wave covers 1 KiB + apron per load), reduces them horizontally to 4 values and
+// keeps the last 5 horizontally-reduced rows in registers; every second input row it emits one output
+// row.  Horizontal-then-vertical is the same linear operator as the reference's vertical-then-
+// horizontal (the two passes act on different axes); only fp32 rounding order differs (~1e-7).
+constexpr int RSEG = 32;  // output rows per thread
+
+__device__ __forceinline__ void hreduce_row(const ReduceArgs& a, const float* row, int ox, bool first, bool last, float (&h)[4]) {
+  // input columns 2*ox-4 .. 2*ox+11 (three aligned float4 + one more), zero outside the image
+  const int ix = 2 * ox - 4;
+  float v[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int x = ix + 4 * q;
+    float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (x >= 0 && x < a.W) t = *reinterpret_cast<const float4*>(row + x);
+    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  }
+  const float k0 = a.k[0], k1 = a.k[1], k2 = a.k[2], k3 = a.k[3], k4 = a.k[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {  // output column ox+j: taps at input 2(ox+j)-2 .. +2 = v[2j+2 .. 2j+6]
+    h[j] = v[2 * j + 2] * k0 + v[2 * j + 3] * k1 + v[2 * j + 4] * k2 + v[2 * j + 5] * k3 + v[2 * j + 6] * k4;
+  }
+  if (first) h[0] += v[4] * k1 + v[5] * k0;                       // lpyr_dec.py:205 (columns 0 and 1)
+  if (last) {                                                       // output column Wo-1 = ox+3, W even here
+    const int c1 = a.W - 1 - ix, c2 = a.W - 2 - ix;                 // always 11 and 10 for W % 8 == 0
+    if (a.H & 1) h[3] += v[c1] * k3 + v[c2] * k4;                   // sic: row parity (lpyr_dec.py:206-207)
+    else h[3] += v[c1] * k4;                                        // :209
+  }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_vec(ReduceArgs a) {
+  const int img = blockIdx.z;
+  const int plane = img / a.n_img, it = img - plane * a.n_img;
+  const float* in = a.in + ((int64_t)plane * a.img_cap + it) * a.H * a.W;
+  float* out = a.out + ((int64_t)plane * a.img_cap + it) * a.Ho * a.Wo;
+  const int ox = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (ox >= a.Wo) return;
+  const bool first = ox == 0, last = ox + 4 >= a.Wo;
+  const int oy0 = blockIdx.y * RSEG, oy1 = min(oy0 + RSEG, a.Ho);
+  const float k0 = a.k[0], k1 = a.k[1], k2 = a.k[2], k3 = a.k[3], k4 = a.k[4];
+  // window of horizontally reduced input rows y-4 .. y ; rows outside the image are zero (+ edge terms)
+  float w[5][4];
+  auto hrow = [&](int y, float (&h)[4]) {
+    if (y >= 0 && y < a.H) hreduce_row(a, in + (int64_t)y * a.W, ox, first, last, h);
+    else h[0] = h[1] = h[2] = h[3] = 0.0f;
+  };
+#pragma unroll
+  for (int k = 0; k < 3; ++k) hrow(2 * oy0 - 2 + k, w[k]);         // rows 2oy-2, 2oy-1, 2oy of the first output
+  for (int oy = oy0; oy < oy1; ++oy) {
+    if (oy > oy0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { w[0][j] = w[2][j]; w[1][j] = w[3][j]; w[2][j] = w[4][j]; }
+    }
+    hrow(2 * oy + 1, w[3]);
+    hrow(2 * oy + 2, w[4]);
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = w[0][j] * k0 + w[1][j] * k1 + w[2][j] * k2 + w[3][j] * k3 + w[4][j] * k4;
+    if (oy == 0) {                                                   // lpyr_dec.py:195: rows 0 and 1 = w[2], w[3]
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] += w[2][j] * k1 + w[3][j] * k0;
+    }
+    if (oy == a.Ho - 1) {                                            // :196-199
+      if (a.H & 1) {                                                 // centre row H-1 = w[2]; row H-2 = w[1]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += w[2][j] * k3 + w[1][j] * k4;
+      } else {                                                       // centre row H-2 = w[2]; row H-1 = w[3]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += w[3][j] * k4;
+      }
+    }
+    *reinterpret_cast<float4*>(out + (int64_t)oy * a.Wo + ox) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 void launch_reduce(const ReduceArgs& a, hipStream_t s) {
+  if (a.W % 8 == 0 && a.H >= 4) {
+    dim3 grid((a.Wo / 4 + 255) / 256, (a.Ho + RSEG - 1) / RSEG, a.n_planes * a.n_img);
+    hipLaunchKernelGGL(k_reduce_vec, grid, dim3(256), 0, s, a);
+    return;
+  }
   dim3 grid((a.Wo + RT - 1) / RT, (a.Ho + RT - 1) / RT, a.n_planes * a.n_img);
   hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, s, a);
 }

@@ -1,0 +1,298 @@
+// K3..K7 fused, vectorised variant for wide levels (W % 8 == 0): same arithmetic as band.hip, laid out
+// for CDNA4 memory instructions.
+//
+//   wave  <-> colour/temporal channel c (so q_c, the cross-channel weights into c and the CSF row of c
+//             are wave-uniform scalars)
+//   lane  <-> 4 adjacent columns        (16-byte global loads of g, ds_read_b128/ds_write_b128 for every
+//             per-row exchange, 4 independent SFU chains per lane)
+//   block <-> strip of 240 interior columns (+8 aligned halo columns each side), marching down a row
+//             segment exactly like k_band.
+//
+// Two barriers per row.  Global loads for row r+1 (coarse rows for the expand, g prefetch) are issued in
+// the second phase of row r, behind ~100 FMAs of blur, so HBM latency is off the critical path:
+//
+//   phase 1:  pooling stage of the row finished last iteration (reads s_q of all channels, s_d)
+//             contrast/CSF stage of row r (reads s_ve, writes s_m and the s_d ring)
+//   barrier
+//   phase 2:  13-tap horizontal blur (5 ds_read_b128), 13-row register window, vertical blur,
+//             Mq = safe_pow(blur*10^mask_c, q_c) -> s_q ; vertical expand of row r+1 -> s_ve ; prefetch g
+//   barrier
+//
+// Image-edge halo columns are produced by the in-image lanes as mirrored LDS writes (reflect padding
+// of the blur), halo rows by evaluating the reflected row.
+#include "kernels.h"
+
+namespace cvvdp {
+
+constexpr int B4_R = 6;            // blur radius
+constexpr int B4_BW = 13;
+constexpr int B4_HALO = 8;         // aligned halo columns per side
+constexpr int B4_SW = 256 - 2 * B4_HALO;  // 240 interior columns per strip
+constexpr int B4_VE = 132;         // s_ve row: [0] = coarse col cb-1 (unused), [1+i] = coarse col cb+i
+
+struct f4 { float v[4]; };
+
+__device__ __forceinline__ f4 lds_read4(const float* p) {
+  const float4 q = *reinterpret_cast<const float4*>(p);
+  return f4{{q.x, q.y, q.z, q.w}};
+}
+__device__ __forceinline__ void lds_write4(float* p, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <int S>
+__device__ __forceinline__ void win4_step(float (&win)[B4_BW][4], const float (&h)[4], const float* bw, float (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) win[S][i] = h[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < B4_BW; ++j) acc += bw[j] * win[(S + 1 + j) % B4_BW][i];
+    v[i] = acc;
+  }
+}
+
+__device__ __forceinline__ int refl(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(64 * NCH) void k_band4(BandArgs a) {
+  constexpr int NP = 2 * NCH;
+  __shared__ __attribute__((aligned(16))) float s_ve[NP][B4_VE];
+  __shared__ __attribute__((aligned(16))) float s_m[NCH][256];
+  __shared__ __attribute__((aligned(16))) float s_q[NCH][256];
+  __shared__ __attribute__((aligned(16))) float s_d[B4_R + 1][NCH][256];
+  __shared__ float s_lut[NCH][CVVDP_CSF_NODES];
+
+  const int t = threadIdx.x;
+  const int c = t >> 6, j = t & 63;                 // channel (wave), lane
+  const int strip = blockIdx.x, seg = blockIdx.y, item = blockIdx.z;
+  const int H = a.H, W = a.W, Hc = a.Hc, Wc = a.Wc;
+  const int x0 = strip * B4_SW;
+  const int fc0 = x0 - B4_HALO + 4 * j;             // first of this lane's 4 columns
+  const bool in_img = fc0 >= 0 && fc0 < W;          // all four in or all four out (W % 4 == 0)
+  const bool interior = j >= 2 && j < 62 && fc0 < W;  // columns whose result is pooled
+  const int cb = (x0 - B4_HALO) / 2;                // coarse column of s_ve[.][1]
+  const int ys = seg * a.seg_h, ye = min(H, ys + a.seg_h);
+
+  const int64_t P = (int64_t)H * W, Pc = (int64_t)Hc * Wc;
+  const int64_t gps = (int64_t)a.items_cap * P, gcps = (int64_t)a.items_cap * Pc;
+  const float* gT = a.g + (int64_t)item * P + (2 * c) * gps;      // test plane of this channel
+  const float* gR = gT + gps;                                      // reference plane
+  // stage-1 role of this lane: plane 2c + (j>>5), coarse chunk j&31
+  const int vp = 2 * c + (j >> 5);
+  const int vch = j & 31;
+  const int vcx = cb + 4 * vch;                                    // first coarse column of the chunk
+  const float* gcp = a.gc + (int64_t)item * Pc + vp * gcps;
+
+  for (int i = t; i < NCH * CVVDP_CSF_NODES; i += 64 * NCH) {
+    const int cc = i / CVVDP_CSF_NODES;
+    // log2-domain CSF row with the constant gains folded in: S*ch_gain = 2^(lut*log2(10) + log2(sens_mul*ch_gain))
+    s_lut[cc][i - cc * CVVDP_CSF_NODES] = a.lut[i] * kLog2_10 + fast_log2(a.sens_mul * a.ch_gain[cc]);
+  }
+  const float e0 = a.kx[0], e1 = a.kx[1], eo = a.kx[2];
+  const float ind_scale = (float)(CVVDP_CSF_NODES - 1) / (a.logL_last - a.logL_first);
+  const float qc = a.q[c], eps_qc = a.eps_q[c];
+  const float xw0 = a.xw[0 * 4 + c], xw1 = a.xw[1 * 4 + c], xw2 = a.xw[2 * 4 + c], xw3 = a.xw[3 * 4 + c];
+
+  // vertical half of the expand for fine row rr -> s_ve (lpyr_dec.py:229-232)
+  auto stage1 = [&](int rr) {
+    const int my = rr >> 1;
+    const int ya = max(my - 1, 0), yb = min(my + 1, Hc - 1);
+    const int cx = min(max(vcx, 0), Wc - 4);
+    const bool clampL = vcx < 0, clampR = vcx >= Wc;
+    auto ld = [&](int y) -> f4 {
+      const float4 q = *reinterpret_cast<const float4*>(gcp + (int64_t)y * Wc + cx);
+      if (clampL) return f4{{q.x, q.x, q.x, q.x}};
+      if (clampR) return f4{{q.w, q.w, q.w, q.w}};
+      return f4{{q.x, q.y, q.z, q.w}};
+    };
+    float o[4];
+    if (rr & 1) {
+      const f4 m0 = ld(my), m1 = ld(yb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = m0.v[i] * eo + m1.v[i] * eo;
+    } else {
+      const f4 m0 = ld(ya), m1 = ld(my), m2 = ld(yb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = m0.v[i] * e0 + m1.v[i] * e1 + m2.v[i] * e0;
+    }
+    // element 1+i of the row <-> coarse column cb+i ; 4*vch+1 is not 16-byte aligned -> scalar stores
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_ve[vp][1 + 4 * vch + i] = o[i];
+  };
+
+  // horizontal half of the expand for this lane's 4 columns from 4 coarse values (lpyr_dec.py:234-237)
+  auto expand4 = [&](const float* row, float (&ex)[4]) {
+    const float2 ab = *reinterpret_cast<const float2*>(row + 2 * j);       // coarse cb+2j-1, cb+2j
+    const float2 cd = *reinterpret_cast<const float2*>(row + 2 * j + 2);   // coarse cb+2j+1, cb+2j+2
+    ex[0] = ab.x * e0 + ab.y * e1 + cd.x * e0;
+    ex[1] = ab.y * eo + cd.x * eo;
+    ex[2] = ab.y * e0 + cd.x * e1 + cd.y * e0;
+    ex[3] = cd.x * eo + cd.y * eo;
+  };
+
+  float win[B4_BW][4];
+#pragma unroll
+  for (int k = 0; k < B4_BW; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) win[k][i] = 0.0f;
+  float acc = 0.0f;
+
+  // pooling stage of centre row y (cvvdp_metric.py:849-856, 722): needs s_q of all channels and s_d
+  auto stage3c = [&](int y) {
+    const int ds = ((y % (B4_R + 1)) + (B4_R + 1)) % (B4_R + 1);
+    const f4 q0 = lds_read4(&s_q[0][4 * j]), q1 = lds_read4(&s_q[1][4 * j]), q2 = lds_read4(&s_q[2][4 * j]);
+    f4 q3 = f4{{0.0f, 0.0f, 0.0f, 0.0f}};
+    if constexpr (NCH == 4) q3 = lds_read4(&s_q[3][4 * j]);
+    const f4 d = lds_read4(&s_d[ds][c][4 * j]);
+    float D[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float M = q0.v[i] * xw0 + q1.v[i] * xw1 + q2.v[i] * xw2 + q3.v[i] * xw3;     // cvvdp_metric.py:758-760
+      const float Du = (fast_pow(d.v[i] + kEps, a.mask_p) - a.eps_p) * fast_rcp(1.0f + M);
+      D[i] = a.dmax * Du * fast_rcp(a.dmax + Du);                                          // :949-950
+      const float de = D[i] + kEps;
+      acc += de * de - kEps * kEps;
+    }
+    if (a.ddump) *reinterpret_cast<float4*>(a.ddump + (int64_t)c * a.items_cap * P + (int64_t)item * P + (int64_t)y * W + fc0) =
+        make_float4(D[0], D[1], D[2], D[3]);
+  };
+
+  // ---- prologue: expand row and g prefetch for the first row
+  int r = ys - B4_R;
+  int rr = refl(r, H);
+  stage1(rr);
+  float4 pT = make_float4(0, 0, 0, 0), pR = make_float4(0, 0, 0, 0);
+  if (in_img) {
+    pT = *reinterpret_cast<const float4*>(gT + (int64_t)rr * W + fc0);
+    pR = *reinterpret_cast<const float4*>(gR + (int64_t)rr * W + fc0);
+  }
+  __syncthreads();
+
+  for (; r < ye + B4_R; ++r) {
+    // ================= phase 1
+    const int yprev = r - 1 - B4_R;                  // row whose Mq was published last iteration
+    if (interior && yprev >= ys) stage3c(yprev);
+    float m[4] = {0.0f, 0.0f, 0.0f, 0.0f}, d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (in_img) {
+      float exT[4], exR[4], eyT[4], eyR[4];
+      expand4(&s_ve[2 * c][0], exT);
+      expand4(&s_ve[2 * c + 1][0], exR);
+      if (c == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { eyT[i] = exT[i]; eyR[i] = exR[i]; }
+      } else {
+        expand4(&s_ve[0][0], eyT);
+        expand4(&s_ve[1][0], eyR);
+      }
+      const float gt[4] = {pT.x, pT.y, pT.z, pT.w}, gr[4] = {pR.x, pR.y, pR.z, pR.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float Lt = fmaxf(eyT[i], 0.01f), Lr = fmaxf(eyR[i], 0.01f);      // lpyr_dec.py:394
+        const float rLt = fast_rcp(Lt), rLr = fast_rcp(Lr);
+        float ind = (fast_log2(Lr) * kLog10_2 - a.logL_first) * ind_scale;     // lpyr_dec.py:408, interp.py:93
+        ind = fminf(fmaxf(ind, 0.0f), (float)(CVVDP_CSF_NODES - 1));
+        const int i0 = (int)ind;
+        const float fr = ind - (float)i0;
+        const int i1 = min(i0 + 1, CVVDP_CSF_NODES - 1);
+        const float l0 = s_lut[c][i0], l1 = s_lut[c][i1];
+        const float S = fast_exp2(l0 + (l1 - l0) * fr);                        // csf.py:49, cvvdp_metric.py:709,:836
+        const float ct = fminf((gt[i] - exT[i]) * rLt, 1000.0f) * a.band_mul;  // lpyr_dec.py:402, :66
+        const float cr = fminf((gr[i] - exR[i]) * rLr, 1000.0f) * a.band_mul;
+        const float Tp = ct * S, Rp = cr * S;
+        m[i] = fminf(fabsf(Tp), fabsf(Rp));                                    // cvvdp_metric.py:845
+        d[i] = fabsf(Tp - Rp);
+      }
+      lds_write4(&s_m[c][4 * j], m);
+      const int ds = ((r % (B4_R + 1)) + (B4_R + 1)) % (B4_R + 1);
+      lds_write4(&s_d[ds][c][4 * j], d);
+      // reflect padding of the blur at the image's left/right edge: mirror columns 1..6 / W-7..W-2
+      if (fc0 < 8) {                                  // strip 0, lanes holding columns 0..7
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int x = fc0 + i;
+          if (x >= 1 && x <= B4_R) s_m[c][B4_HALO - x] = m[i];               // column -x
+        }
+      }
+      if (fc0 + 8 >= W) {                             // lanes holding columns W-8..W-1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int x = fc0 + i;
+          const int idx = 2 * (W - 1) - x - (x0 - B4_HALO);                  // column 2(W-1)-x
+          if (x <= W - 2 && x >= W - 1 - B4_R && idx < 256) s_m[c][idx] = m[i];
+        }
+      }
+    }
+    __syncthreads();
+    // ================= phase 2
+    const int yc = r - B4_R;
+    if (interior) {
+      const float* row = &s_m[c][4 * j - 8];
+      const f4 a0 = lds_read4(row), a1 = lds_read4(row + 4), a2 = lds_read4(row + 8), a3 = lds_read4(row + 12), a4 = lds_read4(row + 16);
+      const float x[20] = {a0.v[0], a0.v[1], a0.v[2], a0.v[3], a1.v[0], a1.v[1], a1.v[2], a1.v[3], a2.v[0], a2.v[1],
+                           a2.v[2], a2.v[3], a3.v[0], a3.v[1], a3.v[2], a3.v[3], a4.v[0], a4.v[1], a4.v[2], a4.v[3]};
+      float h[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                   // output column 4j+i: taps at x[i+2 .. i+14]
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < B4_BW; ++k) s += a.blur[k] * x[i + 2 + k];
+        h[i] = s;
+      }
+      float v[4];
+      const int slot = (r - (ys - B4_R)) % B4_BW;
+      switch (slot) {
+        case 0: win4_step<0>(win, h, a.blur, v); break;
+        case 1: win4_step<1>(win, h, a.blur, v); break;
+        case 2: win4_step<2>(win, h, a.blur, v); break;
+        case 3: win4_step<3>(win, h, a.blur, v); break;
+        case 4: win4_step<4>(win, h, a.blur, v); break;
+        case 5: win4_step<5>(win, h, a.blur, v); break;
+        case 6: win4_step<6>(win, h, a.blur, v); break;
+        case 7: win4_step<7>(win, h, a.blur, v); break;
+        case 8: win4_step<8>(win, h, a.blur, v); break;
+        case 9: win4_step<9>(win, h, a.blur, v); break;
+        case 10: win4_step<10>(win, h, a.blur, v); break;
+        case 11: win4_step<11>(win, h, a.blur, v); break;
+        default: win4_step<12>(win, h, a.blur, v); break;
+      }
+      if (yc >= ys) {
+        float Mq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Mq[i] = fast_pow(fabsf(v[i] * a.mask_c10) + kEps, qc) - eps_qc;   // cvvdp_metric.py:849
+        lds_write4(&s_q[c][4 * j], Mq);
+      }
+    }
+    if (r + 1 < ye + B4_R) {
+      rr = refl(r + 1, H);
+      stage1(rr);
+      if (in_img) {
+        pT = *reinterpret_cast<const float4*>(gT + (int64_t)rr * W + fc0);
+        pR = *reinterpret_cast<const float4*>(gR + (int64_t)rr * W + fc0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: pooling stage of the last centre row
+  if (interior && (ye - 1) >= ys) stage3c(ye - 1);
+
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (j == 0) {
+    const int nblk = a.n_strip * a.n_seg;
+    a.partial[((int64_t)item * nblk + (seg * a.n_strip + strip)) * 4 + c] = acc;
+  }
+}
+
+void launch_band4(const BandArgs& a, hipStream_t s) {
+  dim3 grid(a.n_strip, a.n_seg, a.items);
+  if (a.nch == 4) hipLaunchKernelGGL((k_band4<4>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_band4<3>), grid, dim3(192), 0, s, a);
+}
+
+}  // namespace cvvdp

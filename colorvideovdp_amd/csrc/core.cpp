@@ -20,6 +20,7 @@ struct Level {
   size_t g_off = 0, heat_off = 0, dd_off = 0;  // float offsets into the workspace
   int n_strip = 1, n_seg = 1, seg_h = 1;
   bool blur = false;
+  bool vec4 = false;  // level is handled by k_band4
 };
 
 struct ProfEvent { hipEvent_t a, b; int cat; };
@@ -134,7 +135,8 @@ int run_pyramid_and_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, hip
     heat_weights(h, false, a.hw);
     a.beta_tch = h->p.beta_tch; a.eps_btch = std::pow(kEps, h->p.beta_tch); a.eps_inv_btch = std::pow(kEps, 1.0f / h->p.beta_tch);
     a.ddump = h->c.debug_dump ? h->ws + lv.dd_off : nullptr;
-    launch_band(a, lv.blur, s);
+    if (lv.vec4) launch_band4(a, s);
+    else launch_band(a, lv.blur, s);
     FinalizeArgs f{};
     f.partial = a.partial; f.items = items; f.nblk = lv.n_strip * lv.n_seg; f.nch = nch; f.P = (int)lv.P;
     f.q_out = h->ws + h->q_off; f.q_frames = h->c.n_frames; f.q_levels = L; f.q_frame_offset = q_frame_offset;
@@ -224,7 +226,8 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     Level& lv = h->lv[l];
     lv.H = H; lv.W = W; lv.P = (int64_t)H * W;
     lv.blur = pad > 0 && H > pad && W > pad;
-    const int sw = lv.blur ? 256 - 2 * pad : 256;
+    lv.vec4 = lv.blur && (W % 8 == 0) && c.heatmap == CVVDP_HEATMAP_NONE;
+    const int sw = lv.vec4 ? kBand4StripWidth : (lv.blur ? 256 - 2 * pad : 256);
     lv.n_strip = (W + sw - 1) / sw;
     lv.n_seg = (H + 127) / 128;
     lv.seg_h = (H + lv.n_seg - 1) / lv.n_seg;

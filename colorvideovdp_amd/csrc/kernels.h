@@ -88,6 +88,8 @@ struct BandArgs {
   float* ddump;      // debug [4][items_cap][H*W] or null
 };
 void launch_band(const BandArgs& a, bool blur, hipStream_t s);
+void launch_band4(const BandArgs& a, hipStream_t s);   // vectorised variant: W % 8 == 0, blur on, no heat map
+constexpr int kBand4StripWidth = 240;
 
 struct BaseArgs {
   const float* g;    // baseband planes [2*nch][items_cap][P]

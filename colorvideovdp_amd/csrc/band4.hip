@@ -28,7 +28,7 @@ constexpr int B4_R = 6;            // blur radius
 constexpr int B4_BW = 13;
 constexpr int B4_HALO = 8;         // aligned halo columns per side
 constexpr int B4_SW = 256 - 2 * B4_HALO;  // 240 interior columns per strip
-constexpr int B4_VE = 132;         // s_ve row: [0] = coarse col cb-1 (unused), [1+i] = coarse col cb+i
+constexpr int B4_VE = 136;         // s_ve row: element 4+i = coarse column cb+i (i = 0..127), 16-byte aligned chunks
 
 struct f4 { float v[4]; };
 
@@ -60,7 +60,7 @@ __device__ __forceinline__ int refl(int i, int n) {
 }
 
 template <int NCH>
-__global__ __launch_bounds__(64 * NCH) void k_band4(BandArgs a) {
+__global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   constexpr int NP = 2 * NCH;
   __shared__ __attribute__((aligned(16))) float s_ve[NP][B4_VE];
   __shared__ __attribute__((aligned(16))) float s_m[NCH][256];
@@ -99,41 +99,47 @@ __global__ __launch_bounds__(64 * NCH) void k_band4(BandArgs a) {
   const float qc = a.q[c], eps_qc = a.eps_q[c];
   const float xw0 = a.xw[0 * 4 + c], xw1 = a.xw[1 * 4 + c], xw2 = a.xw[2 * 4 + c], xw3 = a.xw[3 * 4 + c];
 
-  // vertical half of the expand for fine row rr -> s_ve (lpyr_dec.py:229-232)
-  auto stage1 = [&](int rr) {
+  // vertical half of the expand for fine row rr -> s_ve (lpyr_dec.py:229-232), split in two so that the
+  // global loads are issued a whole row-iteration before their values are needed
+  const int cx = min(max(vcx, 0), Wc - 4);
+  const bool clampL = vcx < 0, clampR = vcx >= Wc;
+  float4 cA, cB, cC;    // coarse rows my-1, my, my+1 (clamped) of the chunk
+  auto stage1_load = [&](int rr) {
     const int my = rr >> 1;
     const int ya = max(my - 1, 0), yb = min(my + 1, Hc - 1);
-    const int cx = min(max(vcx, 0), Wc - 4);
-    const bool clampL = vcx < 0, clampR = vcx >= Wc;
-    auto ld = [&](int y) -> f4 {
-      const float4 q = *reinterpret_cast<const float4*>(gcp + (int64_t)y * Wc + cx);
+    cA = *reinterpret_cast<const float4*>(gcp + (int64_t)ya * Wc + cx);
+    cB = *reinterpret_cast<const float4*>(gcp + (int64_t)my * Wc + cx);
+    cC = *reinterpret_cast<const float4*>(gcp + (int64_t)yb * Wc + cx);
+  };
+  auto stage1_finish = [&](int rr) {
+    auto fix = [&](const float4& q) -> f4 {
       if (clampL) return f4{{q.x, q.x, q.x, q.x}};
       if (clampR) return f4{{q.w, q.w, q.w, q.w}};
       return f4{{q.x, q.y, q.z, q.w}};
     };
+    const f4 m0 = fix(cA), m1 = fix(cB), m2 = fix(cC);
     float o[4];
     if (rr & 1) {
-      const f4 m0 = ld(my), m1 = ld(yb);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = m0.v[i] * eo + m1.v[i] * eo;
+      for (int i = 0; i < 4; ++i) o[i] = m1.v[i] * eo + m2.v[i] * eo;
     } else {
-      const f4 m0 = ld(ya), m1 = ld(my), m2 = ld(yb);
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = m0.v[i] * e0 + m1.v[i] * e1 + m2.v[i] * e0;
     }
-    // element 1+i of the row <-> coarse column cb+i ; 4*vch+1 is not 16-byte aligned -> scalar stores
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s_ve[vp][1 + 4 * vch + i] = o[i];
+    lds_write4(&s_ve[vp][4 + 4 * vch], o);
   };
 
   // horizontal half of the expand for this lane's 4 columns from 4 coarse values (lpyr_dec.py:234-237)
   auto expand4 = [&](const float* row, float (&ex)[4]) {
-    const float2 ab = *reinterpret_cast<const float2*>(row + 2 * j);       // coarse cb+2j-1, cb+2j
-    const float2 cd = *reinterpret_cast<const float2*>(row + 2 * j + 2);   // coarse cb+2j+1, cb+2j+2
-    ex[0] = ab.x * e0 + ab.y * e1 + cd.x * e0;
-    ex[1] = ab.y * eo + cd.x * eo;
-    ex[2] = ab.y * e0 + cd.x * e1 + cd.y * e0;
-    ex[3] = cd.x * eo + cd.y * eo;
+    // coarse cb+2j-1 .. cb+2j+2 live at elements 2j+3 .. 2j+6: three aligned ds_read_b64 (conflict-free)
+    const float2 p0 = *reinterpret_cast<const float2*>(row + 2 * j + 2);
+    const float2 p1 = *reinterpret_cast<const float2*>(row + 2 * j + 4);
+    const float2 p2 = *reinterpret_cast<const float2*>(row + 2 * j + 6);
+    const float A = p0.y, B = p1.x, C = p1.y, D = p2.x;
+    ex[0] = A * e0 + B * e1 + C * e0;
+    ex[1] = B * eo + C * eo;
+    ex[2] = B * e0 + C * e1 + D * e0;
+    ex[3] = C * eo + D * eo;
   };
 
   float win[B4_BW][4];
@@ -154,8 +160,9 @@ __global__ __launch_bounds__(64 * NCH) void k_band4(BandArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float M = q0.v[i] * xw0 + q1.v[i] * xw1 + q2.v[i] * xw2 + q3.v[i] * xw3;     // cvvdp_metric.py:758-760
-      const float Du = (fast_pow(d.v[i] + kEps, a.mask_p) - a.eps_p) * fast_rcp(1.0f + M);
-      D[i] = a.dmax * Du * fast_rcp(a.dmax + Du);                                          // :949-950
+      // Du = X/(1+M); D = dmax*Du/(dmax+Du) = dmax*X / (dmax*(1+M) + X): one reciprocal (:855-856, :949-950)
+      const float X = fast_pow(d.v[i] + kEps, a.mask_p) - a.eps_p;
+      D[i] = a.dmax * X * fast_rcp(a.dmax + a.dmax * M + X);
       const float de = D[i] + kEps;
       acc += de * de - kEps * kEps;
     }
@@ -166,12 +173,13 @@ __global__ __launch_bounds__(64 * NCH) void k_band4(BandArgs a) {
   // ---- prologue: expand row and g prefetch for the first row
   int r = ys - B4_R;
   int rr = refl(r, H);
-  stage1(rr);
+  stage1_load(rr);
   float4 pT = make_float4(0, 0, 0, 0), pR = make_float4(0, 0, 0, 0);
   if (in_img) {
     pT = *reinterpret_cast<const float4*>(gT + (int64_t)rr * W + fc0);
     pR = *reinterpret_cast<const float4*>(gR + (int64_t)rr * W + fc0);
   }
+  stage1_finish(rr);
   __syncthreads();
 
   for (; r < ye + B4_R; ++r) {
@@ -230,6 +238,18 @@ __global__ __launch_bounds__(64 * NCH) void k_band4(BandArgs a) {
     }
     __syncthreads();
     // ================= phase 2
+    // issue next row's global loads right after the barrier; they are consumed at the end of this phase
+    // (coarse rows -> s_ve) and in the next phase 1 (g), i.e. behind the ~120 FMAs of the blur
+    const bool more = r + 1 < ye + B4_R;
+    const int rn = refl(r + 1, H);
+    float4 nT = make_float4(0, 0, 0, 0), nR = make_float4(0, 0, 0, 0);
+    if (more) {
+      stage1_load(rn);
+      if (in_img) {
+        nT = *reinterpret_cast<const float4*>(gT + (int64_t)rn * W + fc0);
+        nR = *reinterpret_cast<const float4*>(gR + (int64_t)rn * W + fc0);
+      }
+    }
     const int yc = r - B4_R;
     if (interior) {
       const float* row = &s_m[c][4 * j - 8];
@@ -268,13 +288,10 @@ __global__ __launch_bounds__(64 * NCH) void k_band4(BandArgs a) {
         lds_write4(&s_q[c][4 * j], Mq);
       }
     }
-    if (r + 1 < ye + B4_R) {
-      rr = refl(r + 1, H);
-      stage1(rr);
-      if (in_img) {
-        pT = *reinterpret_cast<const float4*>(gT + (int64_t)rr * W + fc0);
-        pR = *reinterpret_cast<const float4*>(gR + (int64_t)rr * W + fc0);
-      }
+    if (more) {
+      stage1_finish(rn);
+      pT = nT;
+      pR = nR;
     }
     __syncthreads();
   }

@@ -229,7 +229,7 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     lv.vec4 = lv.blur && (W % 8 == 0) && c.heatmap == CVVDP_HEATMAP_NONE;
     const int sw = lv.vec4 ? kBand4StripWidth : (lv.blur ? 256 - 2 * pad : 256);
     lv.n_strip = (W + sw - 1) / sw;
-    lv.n_seg = (H + 127) / 128;
+    lv.n_seg = (H + 255) / 256;
     lv.seg_h = (H + lv.n_seg - 1) / lv.n_seg;
     if (l + 1 < h->L && (H < 2 || W < 2)) return fail(h, CVVDP_E_ARG, "pyramid too deep for %dx%d", c.width, c.height);
     H = (H + 1) / 2; W = (W + 1) / 2;

@@ -20,7 +20,7 @@ def main(path):
         print("%-92s %7d %12.3f %11.1f %11.1f %11.1f %6.2f %5s %5s %7s %s..%s" % (nm, c, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total, vg, sg, lds, g0, g1))
     print("# total GPU kernel time: %.3f ms" % (total / 1e6))
     try:
-        pm = cur.execute("select k.name, p.counter_name, count(*), sum(p.value) from pmc_events p join kernels k on p.event_id = k.event_id "
+        pm = cur.execute("select k.name, p.counter_name, count(*), sum(p.counter_value) from pmc_events p join kernels k on p.event_id = k.event_id "
                          "group by k.name, p.counter_name order by k.name").fetchall()
     except sqlite3.Error as e:
         pm = []

@@ -12,11 +12,11 @@ MAX_WINDOW = 256
 CSF_NODES = 32
 PROF_N = 6
 PROF_NAMES = ("photometry", "temporal_fir", "pyr_reduce", "band_level0", "band_rest", "heatmap")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 U8, U16, F16, F32, F32_DKL = range(5)
 HEATMAP = {None: 0, "none": 0, "raw": 1, "threshold": 2, "supra-threshold": 3}
-BUF_RING, BUF_GPYR, BUF_DDUMP, BUF_HEAT, BUF_Q = range(5)
+BUF_HIST, BUF_GPYR, BUF_DDUMP, BUF_HEAT, BUF_Q = range(5)
 
 
 class Params(C.Structure):
@@ -51,7 +51,6 @@ class Clip(C.Structure):
         ("n_levels", C.c_int32),
         ("filter_len", C.c_int32),
         ("block_frames", C.c_int32),
-        ("ring_slots", C.c_int32),
         ("heatmap", C.c_int32),
         ("debug_dump", C.c_int32),
         ("taps", C.c_float * (4 * MAX_FILTER_LEN)),
@@ -68,9 +67,9 @@ SYMBOLS = {
     "cvvdp_configure": (C.c_int, [C.c_void_p, C.POINTER(Clip)]),
     "cvvdp_workspace_bytes": (C.c_size_t, [C.c_void_p]),
     "cvvdp_bind_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
-    "cvvdp_put_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
-                                   C.c_int32, C.c_int32, C.c_void_p]),
-    "cvvdp_process_block": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p]),
+    "cvvdp_put_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
+    "cvvdp_process_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                      C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p]),
     "cvvdp_process_image": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cvvdp_get_q_per_ch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvvdp_pool_jod": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

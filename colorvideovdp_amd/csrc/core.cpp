@@ -33,7 +33,7 @@ struct cvvdp_handle {
   bool configured = false;
   int nch = 4, L = 0, items_cap = 0;
   std::vector<Level> lv;
-  size_t ring_off = 0, partial_off = 0, q_off = 0, hstats_off = 0, hcurve_off = 0;
+  size_t hist_off = 0, hist_shadow_off = 0, partial_off = 0, q_off = 0, hstats_off = 0, hcurve_off = 0;
   size_t ws_floats = 0;
   float* ws = nullptr;
   int last_items = 0;
@@ -212,7 +212,6 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
   if (c.is_video) {
     if (c.filter_len < 1 || c.filter_len > CVVDP_MAX_FILTER_LEN) return fail(h, CVVDP_E_UNSUPPORTED, "filter_len %d unsupported (max %d)", c.filter_len, CVVDP_MAX_FILTER_LEN);
     if (c.block_frames < 1 || c.filter_len - 1 + c.block_frames > CVVDP_MAX_WINDOW) return fail(h, CVVDP_E_ARG, "block_frames out of range");
-    if (c.ring_slots < c.filter_len - 1 + c.block_frames || c.ring_slots > 32767) return fail(h, CVVDP_E_ARG, "ring_slots too small");
   }
   if (c.heatmap != CVVDP_HEATMAP_NONE && c.batch != 1) return fail(h, CVVDP_E_UNSUPPORTED, "heat maps need batch == 1");
   h->c = c;
@@ -238,8 +237,12 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
   // ---- workspace plan (float offsets)
   size_t off = 0;
   const size_t P0 = (size_t)h->lv[0].P;
-  h->ring_off = off;
-  if (c.is_video) off += align_up((size_t)2 * 3 * c.ring_slots * c.batch * P0);
+  h->hist_off = h->hist_shadow_off = off;
+  if (c.is_video && c.filter_len > 1) {
+    const size_t hist = align_up((size_t)2 * 3 * (c.filter_len - 1) * c.batch * P0);
+    off += hist;
+    if (!fir_has_register_window(c.filter_len)) { h->hist_shadow_off = off; off += hist; }  // generic-FL path double-buffers the tail
+  }
   for (auto& lv : h->lv) { lv.g_off = off; off += align_up((size_t)2 * h->nch * h->items_cap * lv.P); }
   size_t pmax = 0;
   for (auto& lv : h->lv) pmax = std::max(pmax, (size_t)h->items_cap * lv.n_strip * lv.n_seg * 4);
@@ -268,36 +271,33 @@ int cvvdp_bind_workspace(cvvdp_handle* h, void* dev, size_t bytes) {
   return CVVDP_OK;
 }
 
-int cvvdp_put_frames(cvvdp_handle* h, const void* t, const void* r, int32_t dtype, const int64_t st[5], const int64_t sr[5],
-                     int32_t first_slot, int32_t n_frames, void* stream) {
+static void fill_display(const cvvdp_handle* h, DisplayArgs& d) {
+  d.eotf = h->p.eotf; d.channels = h->c.channels;
+  d.Y_peak = h->p.Y_peak; d.Y_black = h->p.Y_black; d.Y_refl = h->p.Y_refl;
+  d.exposure = h->p.exposure; d.gamma = h->p.gamma;
+  d.scale = (float)((double)h->p.Y_peak - (double)h->p.Y_black);
+  d.lin_lo = std::max(0.005f, h->p.Y_black);
+  d.hlg_c = (float)(0.5 - 0.17883277 * std::log(4.0 * 0.17883277));
+  for (int i = 0; i < 9; ++i) d.m[i] = h->p.rgb2dkl[i];
+}
+
+int cvvdp_put_image(cvvdp_handle* h, const void* t, const void* r, int32_t dtype, const int64_t st[5], const int64_t sr[5], void* stream) {
   if (!h || !h->ws) return fail(h, CVVDP_E_STATE, "no workspace bound");
-  if (!t || !r || !st || !sr || n_frames < 1) return fail(h, CVVDP_E_ARG, "bad frame arguments");
+  if (!t || !r || !st || !sr) return fail(h, CVVDP_E_ARG, "bad frame arguments");
   if (dtype < CVVDP_U8 || dtype > CVVDP_F32_DKL) return fail(h, CVVDP_E_UNSUPPORTED, "dtype %d unsupported", dtype);
   const cvvdp_clip& c = h->c;
+  if (c.is_video) return fail(h, CVVDP_E_STATE, "configured for video: frames go through cvvdp_process_block");
   hipStream_t s = static_cast<hipStream_t>(stream);
   PhotoArgs a{};
   a.src[0] = t; a.src[1] = r;
   const int64_t* S[2] = {st, sr};
   for (int k = 0; k < 2; ++k) { a.sb[k] = S[k][0]; a.sc[k] = S[k][1]; a.sf[k] = S[k][2]; a.sh[k] = S[k][3]; a.sw[k] = S[k][4]; }
-  a.dtype = dtype; a.channels = c.channels; a.H = c.height; a.W = c.width; a.batch = c.batch; a.n_frames = n_frames;
-  a.eotf = h->p.eotf; a.Y_peak = h->p.Y_peak; a.Y_black = h->p.Y_black; a.Y_refl = h->p.Y_refl;
-  a.exposure = h->p.exposure; a.gamma = h->p.gamma;
-  a.scale = (float)((double)h->p.Y_peak - (double)h->p.Y_black);
-  a.lin_lo = std::max(0.005f, h->p.Y_black);
-  a.hlg_c = (float)(0.5 - 0.17883277 * std::log(4.0 * 0.17883277));
-  for (int i = 0; i < 9; ++i) a.m[i] = h->p.rgb2dkl[i];
+  a.dtype = dtype; a.H = c.height; a.W = c.width; a.batch = c.batch; a.n_frames = 1;
+  fill_display(h, a.dm);
   const int64_t P0 = h->lv[0].P;
-  if (c.is_video) {
-    if (n_frames > c.ring_slots) return fail(h, CVVDP_E_ARG, "more frames than ring slots");
-    a.dst = h->ws + h->ring_off;
-    a.d_b = P0; a.d_slot = (int64_t)c.batch * P0; a.d_ch = (int64_t)c.ring_slots * a.d_slot; a.d_side = 3 * a.d_ch;
-    a.first_slot = ((first_slot % c.ring_slots) + c.ring_slots) % c.ring_slots; a.n_slots = c.ring_slots;
-  } else {
-    if (n_frames != 1) return fail(h, CVVDP_E_ARG, "an image has one frame");
-    a.dst = h->ws + h->lv[0].g_off;
-    a.d_b = P0; a.d_slot = 0; a.d_side = (int64_t)h->items_cap * P0; a.d_ch = 2 * a.d_side;
-    a.first_slot = 0; a.n_slots = 1;
-  }
+  a.dst = h->ws + h->lv[0].g_off;
+  a.d_b = P0; a.d_slot = 0; a.d_side = (int64_t)h->items_cap * P0; a.d_ch = 2 * a.d_side;
+  a.first_slot = 0; a.n_slots = 1;
   {
     ProfScope ps(h, CVVDP_PROF_PHOTOMETRY, s);
     launch_photometry(a, s);
@@ -305,29 +305,40 @@ int cvvdp_put_frames(cvvdp_handle* h, const void* t, const void* r, int32_t dtyp
   return check_launch(h, "photometry");
 }
 
-int cvvdp_process_block(cvvdp_handle* h, const int32_t* window_slots, int32_t n_frames, int32_t q_frame_offset, void* stream) {
+int cvvdp_process_block(cvvdp_handle* h, const void* t, const void* r, int32_t dtype, const int64_t st[5], const int64_t sr[5],
+                        int32_t raw_first, const int32_t* hist_src, int32_t n_frames, int32_t q_frame_offset, void* stream) {
   if (!h || !h->ws) return fail(h, CVVDP_E_STATE, "no workspace bound");
   const cvvdp_clip& c = h->c;
   if (!c.is_video) return fail(h, CVVDP_E_STATE, "configured for an image");
-  if (!window_slots || n_frames < 1 || n_frames > c.block_frames) return fail(h, CVVDP_E_ARG, "n_frames out of range");
+  if (!t || !r || !st || !sr || raw_first < 0) return fail(h, CVVDP_E_ARG, "bad frame arguments");
+  if (dtype < CVVDP_U8 || dtype > CVVDP_F32_DKL) return fail(h, CVVDP_E_UNSUPPORTED, "dtype %d unsupported", dtype);
+  if (n_frames < 1 || n_frames > c.block_frames) return fail(h, CVVDP_E_ARG, "n_frames out of range");
   if (q_frame_offset < 0 || q_frame_offset + n_frames > c.n_frames) return fail(h, CVVDP_E_ARG, "frame offset out of range");
-  hipStream_t s = static_cast<hipStream_t>(stream);
   const int fl = c.filter_len;
+  if (fl > 1 && !hist_src) return fail(h, CVVDP_E_ARG, "hist_src missing");
+  hipStream_t s = static_cast<hipStream_t>(stream);
   FirArgs f{};
   const int64_t P0 = h->lv[0].P;
-  f.ring = h->ws + h->ring_off;
-  f.r_b = P0; f.r_slot = (int64_t)c.batch * P0; f.r_ch = (int64_t)c.ring_slots * f.r_slot; f.r_side = 3 * f.r_ch;
+  f.src[0] = t; f.src[1] = r;
+  const int64_t* S[2] = {st, sr};
+  for (int k = 0; k < 2; ++k) { f.sb[k] = S[k][0]; f.sc[k] = S[k][1]; f.sf[k] = S[k][2]; f.sh[k] = S[k][3]; f.sw[k] = S[k][4]; }
+  f.dtype = dtype;
+  fill_display(h, f.dm);
+  f.W = c.width; f.P = (int)P0; f.batch = c.batch; f.n_frames = n_frames; f.fl = fl;
+  f.raw_first = raw_first; f.write_hist = 1;
+  f.hist = h->ws + h->hist_off;
+  f.h_b = P0; f.h_slot = (int64_t)c.batch * P0; f.h_plane = (int64_t)(fl - 1) * f.h_slot; f.h_side = 3 * f.h_plane;
   f.out = h->ws + h->lv[0].g_off; f.o_plane = (int64_t)h->items_cap * P0;
-  f.P = (int)P0; f.batch = c.batch; f.n_frames = n_frames; f.fl = fl;
   for (int ch = 0; ch < 4; ++ch)
     for (int k = 0; k < fl; ++k) f.taps[ch * CVVDP_MAX_FILTER_LEN + k] = c.taps[ch * CVVDP_MAX_FILTER_LEN + (fl - 1 - k)];  // F.flip(0), :556
-  for (int k = 0; k < fl - 1 + n_frames; ++k) {
-    if (window_slots[k] < 0 || window_slots[k] >= c.ring_slots) return fail(h, CVVDP_E_ARG, "window slot %d out of range", window_slots[k]);
-    f.slots[k] = (int16_t)window_slots[k];
+  for (int k = 0; k < fl - 1; ++k) {
+    const int e = hist_src[k];
+    if (e >= 32767 || e < -(fl - 1)) return fail(h, CVVDP_E_ARG, "hist_src[%d] = %d out of range", k, e);
+    f.hist_src[k] = (int16_t)e;
   }
   {
     ProfScope ps(h, CVVDP_PROF_FIR, s);
-    launch_fir(f, s);
+    launch_fir(f, h->ws + h->hist_shadow_off, s);
   }
   if (int e = check_launch(h, "temporal fir")) return e;
   return run_pyramid_and_bands(h, n_frames, q_frame_offset, s);
@@ -403,9 +414,9 @@ int cvvdp_debug_buffer(cvvdp_handle* h, int32_t which, int32_t level, void** dev
   if (level < 0 || level >= h->L) return fail(h, CVVDP_E_ARG, "bad level");
   const Level& lv = h->lv[level];
   switch (which) {
-    case CVVDP_BUF_RING:
-      if (!h->c.is_video) return fail(h, CVVDP_E_STATE, "no ring for images");
-      *dev_ptr = h->ws + h->ring_off; *n_floats = (size_t)2 * 3 * h->c.ring_slots * h->c.batch * h->lv[0].P; break;
+    case CVVDP_BUF_HIST:
+      if (!h->c.is_video) return fail(h, CVVDP_E_STATE, "no temporal history for images");
+      *dev_ptr = h->ws + h->hist_off; *n_floats = (size_t)2 * 3 * (h->c.filter_len - 1) * h->c.batch * h->lv[0].P; break;
     case CVVDP_BUF_GPYR: *dev_ptr = h->ws + lv.g_off; *n_floats = (size_t)2 * h->nch * h->items_cap * lv.P; break;
     case CVVDP_BUF_DDUMP:
       if (!h->c.debug_dump) return fail(h, CVVDP_E_STATE, "debug_dump not enabled");

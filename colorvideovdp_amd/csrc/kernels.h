@@ -24,16 +24,19 @@ constexpr float kLog2_10 = 3.3219280948873623f;
 constexpr float kLog10_2 = 0.30102999566398120f;
 
 // ---------------------------------------------------------------- photometry + DKL (K0)
+struct DisplayArgs {         // display model, shared by the image and the fused video kernels
+  int32_t eotf, channels;   // CVVDP_EOTF_*; 1 or 3 colour channels in the source
+  float Y_peak, Y_black, Y_refl, exposure, gamma, scale;  // scale = fp32(Y_peak - Y_black)
+  float lin_lo;             // max(0.005, Y_black) for the linear EOTF
+  float hlg_c;              // 0.5 - a*ln(4a)
+  float m[9];               // RGB -> DKL
+};
 struct PhotoArgs {
   const void* src[2];     // test, ref
   int64_t sb[2], sc[2], sf[2], sh[2], sw[2];  // element strides
-  int32_t dtype, channels; // input sample type; 1 or 3 colour channels
+  int32_t dtype;
   int32_t H, W, batch, n_frames;
-  int32_t eotf;
-  float Y_peak, Y_black, Y_refl, exposure, gamma, scale;  // scale = fp32(Y_peak - Y_black)
-  float lin_lo;            // max(0.005, Y_black) for the linear EOTF
-  float hlg_c;             // 0.5 - a*ln(4a)
-  float m[9];
+  DisplayArgs dm;
   float* dst;              // destination base
   int64_t d_side, d_ch, d_slot, d_b;  // element strides of the destination
   int32_t first_slot, n_slots;        // slot = (first_slot + f) % n_slots
@@ -42,15 +45,22 @@ void launch_photometry(const PhotoArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- temporal FIR (K1)
 struct FirArgs {
-  const float* ring;       // [side][ch][slot][b][P]
-  int64_t r_side, r_ch, r_slot, r_b;
+  const void* src[2];      // raw test / reference frames handed to this block
+  int64_t sb[2], sc[2], sf[2], sh[2], sw[2];  // element strides (B, C, F, H, W)
+  int32_t dtype;
+  DisplayArgs dm;
+  int32_t W, P, batch, n_frames, fl;
+  int32_t raw_first;       // raw frame index of the block's first scored frame
+  int32_t write_hist;      // store the last fl-1 DKL frames for the next block
+  float* hist;             // [side][plane][slot][b][P]: DKL tail of the previous block
+  int64_t h_side, h_plane, h_slot, h_b;
   float* out;              // level-0 planes [plane][item][P]
   int64_t o_plane;         // items_cap * P
-  int32_t P, batch, n_frames, fl;
-  float taps[4 * CVVDP_MAX_FILTER_LEN];  // flipped: taps[c][k] multiplies window position k
-  int16_t slots[CVVDP_MAX_WINDOW];
+  float taps[4 * CVVDP_MAX_FILTER_LEN];     // flipped: taps[c][k] multiplies window position k
+  int16_t hist_src[CVVDP_MAX_FILTER_LEN];   // window position k < fl-1: >= 0 raw frame index, < 0 history slot -1-e
 };
-void launch_fir(const FirArgs& a, hipStream_t s);
+void launch_fir(const FirArgs& a, float* hist_shadow, hipStream_t s);
+inline bool fir_has_register_window(int fl) { return fl == 7 || fl == 9 || fl == 13 || fl == 15 || fl == 17 || fl == 25 || fl == 31; }
 
 // ---------------------------------------------------------------- gaussian pyramid reduce (K2)
 struct ReduceArgs {

@@ -1,102 +1,239 @@
-// K1: per-channel temporal FIR over the DKL ring (cvvdp_metric.py:554-560).
-//   R[2c+side][fi] = sum_k ring[side][ch(c)][window fi+k] * F[c][fl-1-k],   ch(3) = 0 (Y transient)
-// The window -> physical slot indirection replaces torch.roll (cvvdp_metric.py:538-539) and the
-// replicate/symmetric padding copies (:506-529).
+// K0+K1 fused for video: sample unpack -> display model -> DKL -> per-channel temporal FIR, one pass.
+//   R[2c+side][fi] = sum_k dkl[side][ch(c)][window fi+k] * F[c][fl-1-k],   ch(3) = 0 (Y transient)
+// Reference: video_source.py:320-346, display_model.py:333-365,266-269, cvvdp_metric.py:453-560.
 //
-// Layout: one thread owns V consecutive pixels of one (colour plane, side, batch) and walks the block's
-// frames in time with a register sliding window of the last FL ring values, so every ring frame is
-// read from HBM once per block (not once per output frame).  The next frame's load is issued before
-// the current frame's FMAs (software prefetch).  The generic-FL fallback re-reads the window.
-#include "kernels.h"
+// A thread owns V adjacent pixels of one (side, batch) for ALL three DKL planes and walks the block's
+// frames in time, keeping the last FL DKL values of each plane in registers.  Consequences:
+//   * every input frame is read from HBM exactly once and converted exactly once; the DKL values of the
+//     block's own frames never touch memory (the reference materialises them in a ring and re-reads the
+//     ring fl times);
+//   * the only DKL state in HBM is the tail of the previous block: the last FL-1 window entries are
+//     written to a (FL-1)-slot history buffer at the end of a block and read back at the start of the
+//     next one (this replaces torch.roll, cvvdp_metric.py:538-539);
+//   * temporal padding (replicate / symmetric, cvvdp_metric.py:506-529) and frame-range shard halos are
+//     expressed by the host as "history entry k = raw frame index e" and converted in the prologue.
+// The next frame's samples are loaded before the current frame's FMAs (software prefetch).
+#include "photometry_dev.h"
 
 namespace cvvdp {
 
-template <int V> struct Vec;
-template <> struct Vec<1> { using T = float; };
-template <> struct Vec<4> { using T = float4; };
-
-__device__ __forceinline__ void vfma(float& acc, float a, float b) { acc += a * b; }
-__device__ __forceinline__ void vfma(float4& acc, const float4& a, float b) {
-  acc.x += a.x * b; acc.y += a.y * b; acc.z += a.z * b; acc.w += a.w * b;
-}
-__device__ __forceinline__ void vzero(float& a) { a = 0.0f; }
-__device__ __forceinline__ void vzero(float4& a) { a = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
-
-template <int FL, int V>
-__global__ __launch_bounds__(256) void k_fir_window(FirArgs a) {
-  using T = typename Vec<V>::T;
-  const int pv = blockIdx.x * 256 + threadIdx.x;     // index of the V-pixel group
-  if (pv * V >= a.P) return;
-  const int c = blockIdx.y % 3, b = blockIdx.y / 3, side = blockIdx.z;
-  const T* rc = reinterpret_cast<const T*>(a.ring + side * a.r_side + c * a.r_ch + b * a.r_b) + pv;
-  const int64_t slot_stride = a.r_slot / V, out_stride = (int64_t)a.batch * a.P / V;
-  const float* tp = a.taps + c * CVVDP_MAX_FILTER_LEN;
-  const float* tt = a.taps + 3 * CVVDP_MAX_FILTER_LEN;
-  T w[FL];
+template <int DT, int V>
+__device__ __forceinline__ void load_pixels(const FirArgs& a, int side, int64_t off, float (&in)[3][V]) {
+  const void* src = a.src[side];
+  if (a.dm.channels == 3) {
 #pragma unroll
-  for (int k = 0; k < FL - 1; ++k) w[k + 1] = rc[(int64_t)a.slots[k] * slot_stride];
-  T* o_s = reinterpret_cast<T*>(a.out + (int64_t)(2 * c + side) * a.o_plane + (int64_t)b * a.P) + pv;
-  T* o_t = reinterpret_cast<T*>(a.out + (int64_t)(6 + side) * a.o_plane + (int64_t)b * a.P) + pv;
-  T nxt = rc[(int64_t)a.slots[FL - 1] * slot_stride];
-  for (int fi = 0; fi < a.n_frames; ++fi) {
+    for (int c = 0; c < 3; ++c) load_run<DT, V>(src, off + c * a.sc[side], in[c]);
+  } else {
+    load_run<DT, V>(src, off, in[0]);
 #pragma unroll
-    for (int k = 0; k < FL - 1; ++k) w[k] = w[k + 1];
-    w[FL - 1] = nxt;
-    if (fi + 1 < a.n_frames) nxt = rc[(int64_t)a.slots[fi + FL] * slot_stride];
-    T acc;
-    vzero(acc);
-#pragma unroll
-    for (int k = 0; k < FL; ++k) vfma(acc, w[k], tp[k]);
-    o_s[(int64_t)fi * out_stride] = acc;
-    if (c == 0) {  // block-uniform
-      T acct;
-      vzero(acct);
-#pragma unroll
-      for (int k = 0; k < FL; ++k) vfma(acct, w[k], tt[k]);
-      o_t[(int64_t)fi * out_stride] = acct;
-    }
+    for (int i = 0; i < V; ++i) in[1][i] = in[2][i] = in[0][i];
   }
 }
 
+template <int DT, int V>
+__device__ __forceinline__ void convert_pixels(const FirArgs& a, const float (&in)[3][V], float (&dkl)[3][V]) {
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    float v[3] = {in[0][i], in[1][i], in[2][i]}, o[3];
+    if constexpr (DT == CVVDP_F32_DKL) {
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    } else {
+      pixel_to_dkl(a.dm, v, o);
+    }
+    dkl[0][i] = o[0]; dkl[1][i] = o[1]; dkl[2][i] = o[2];
+  }
+}
+
+template <int V>
+__device__ __forceinline__ void store_run(float* p, const float (&v)[V]) {
+  if constexpr (V == 1) *p = v[0];
+  else if constexpr (V == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  else *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <int V>
+__device__ __forceinline__ void load_f32_run(const float* p, float (&v)[V]) {
+  if constexpr (V == 1) v[0] = *p;
+  else if constexpr (V == 2) { const float2 q = *reinterpret_cast<const float2*>(p); v[0] = q.x; v[1] = q.y; }
+  else { const float4 q = *reinterpret_cast<const float4*>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+}
+
+template <int DT, int FL, int V>
+__global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
+  const int pix = (blockIdx.x * 256 + threadIdx.x) * V;
+  if (pix >= a.P) return;
+  const int b = blockIdx.y, side = blockIdx.z;
+  const int y = pix / a.W, x = pix - y * a.W;
+  const int64_t off0 = b * a.sb[side] + (int64_t)y * a.sh[side] + (int64_t)x * a.sw[side];
+  const int64_t sf = a.sf[side];
+  float* hist = a.hist + side * a.h_side + b * a.h_b + pix;
+
+  float w[3][FL][V];
+  // ---- prologue: window positions 0..FL-2 (history / temporal padding) go to w[.][1..FL-1]
+#pragma unroll
+  for (int k = 0; k < FL - 1; ++k) {
+    const int e = a.hist_src[k];
+    if (e >= 0) {       // raw frame e of the block handed in by the host
+      float in[3][V], d[3][V];
+      load_pixels<DT, V>(a, side, off0 + e * sf, in);
+      convert_pixels<DT, V>(a, in, d);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < V; ++i) w[p][k + 1][i] = d[p][i];
+    } else {            // slot -1-e of the previous block's tail
+#pragma unroll
+      for (int p = 0; p < 3; ++p) load_f32_run<V>(hist + p * a.h_plane + (int64_t)(-1 - e) * a.h_slot, w[p][k + 1]);
+    }
+  }
+  float* out = a.out + (int64_t)b * a.P + pix;
+  const int64_t o_item = (int64_t)a.batch * a.P;
+  // software prefetch PF frames deep: with ~130 VGPRs only 3 waves/SIMD are resident, so the bytes in
+  // flight per CU have to come from depth (3 waves x 4 SIMDs x PF frames x 3 loads x 512 B ~ 55 KB)
+  constexpr int PF = 3;
+  float pf[PF][3][V];
+#pragma unroll
+  for (int q = 0; q < PF; ++q)
+    if (q < a.n_frames) load_pixels<DT, V>(a, side, off0 + (int64_t)(a.raw_first + q) * sf, pf[q]);
+  for (int fi = 0; fi < a.n_frames; ++fi) {
+    float d[3][V];
+    convert_pixels<DT, V>(a, pf[0], d);
+#pragma unroll
+    for (int q = 0; q + 1 < PF; ++q)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < V; ++i) pf[q][p][i] = pf[q + 1][p][i];
+    if (fi + PF < a.n_frames) load_pixels<DT, V>(a, side, off0 + (int64_t)(a.raw_first + fi + PF) * sf, pf[PF - 1]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int k = 0; k < FL - 1; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) w[p][k][i] = w[p][k + 1][i];
+#pragma unroll
+      for (int i = 0; i < V; ++i) w[p][FL - 1][i] = d[p][i];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {     // Y-sust, RG, YV, Y-trans (window of plane 0 again), cvvdp_metric.py:554-560
+      const int p = (c == 3) ? 0 : c;
+      float acc[V];
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc[i] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < FL; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] += w[p][k][i] * a.taps[c * CVVDP_MAX_FILTER_LEN + k];
+      store_run<V>(out + (int64_t)(2 * c + side) * a.o_plane + (int64_t)fi * o_item, acc);
+    }
+  }
+  // ---- epilogue: the last FL-1 frames become the next block's history
+  if (a.write_hist) {
+#pragma unroll
+    for (int k = 0; k < FL - 1; ++k)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) store_run<V>(hist + p * a.h_plane + (int64_t)k * a.h_slot, w[p][k + 1]);
+  }
+}
+
+// Any filter length (odd frame rates): no register window; every tap re-reads and re-converts its frame.
+template <int DT>
 __global__ __launch_bounds__(256) void k_fir_generic(FirArgs a) {
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= a.P) return;
   const int item = blockIdx.y, side = blockIdx.z;
   const int fi = item / a.batch, b = item - fi * a.batch;
-  const float* rbase = a.ring + side * a.r_side + b * a.r_b + pix;
-  for (int c = 0; c < 3; ++c) {
-    const float* rc = rbase + c * a.r_ch;
-    float acc = 0.0f, acct = 0.0f;
-    for (int k = 0; k < a.fl; ++k) {
-      const float v = rc[(int64_t)a.slots[fi + k] * a.r_slot];
-      acc += v * a.taps[c * CVVDP_MAX_FILTER_LEN + k];
-      if (c == 0) acct += v * a.taps[3 * CVVDP_MAX_FILTER_LEN + k];
+  const int y = pix / a.W, x = pix - y * a.W;
+  const int64_t off0 = b * a.sb[side] + (int64_t)y * a.sh[side] + (int64_t)x * a.sw[side];
+  const float* hist = a.hist + side * a.h_side + b * a.h_b + pix;
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int k = 0; k < a.fl; ++k) {
+    const int pos = fi + k;                                    // window position
+    float d[3][1];
+    const int e = pos < a.fl - 1 ? (int)a.hist_src[pos] : a.raw_first + pos - (a.fl - 1);
+    if (e >= 0) {
+      float in[3][1];
+      load_pixels<DT, 1>(a, side, off0 + e * a.sf[side], in);
+      convert_pixels<DT, 1>(a, in, d);
+    } else {
+      for (int p = 0; p < 3; ++p) d[p][0] = hist[p * a.h_plane + (int64_t)(-1 - e) * a.h_slot];
     }
-    a.out[(int64_t)(2 * c + side) * a.o_plane + (int64_t)item * a.P + pix] = acc;
-    if (c == 0) a.out[(int64_t)(6 + side) * a.o_plane + (int64_t)item * a.P + pix] = acct;
+    for (int c = 0; c < 4; ++c) acc[c] += d[c == 3 ? 0 : c][0] * a.taps[c * CVVDP_MAX_FILTER_LEN + k];
   }
+  for (int c = 0; c < 4; ++c) a.out[(int64_t)(2 * c + side) * a.o_plane + (int64_t)item * a.P + pix] = acc[c];
 }
 
-template <int FL>
-static void launch_window(const FirArgs& a, hipStream_t s) {
-  dim3 block(256);
-  if (a.P % 4 == 0) {
-    dim3 grid((a.P / 4 + 255) / 256, 3 * a.batch, 2);
-    hipLaunchKernelGGL((k_fir_window<FL, 4>), grid, block, 0, s, a);
+// tail of the block -> history, for the generic path (the fused kernel does this itself)
+template <int DT>
+__global__ __launch_bounds__(256) void k_hist_generic(FirArgs a, float* tmp) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= a.P) return;
+  const int k = blockIdx.y % (a.fl - 1), b = blockIdx.y / (a.fl - 1), side = blockIdx.z;
+  const int y = pix / a.W, x = pix - y * a.W;
+  const int64_t off0 = b * a.sb[side] + (int64_t)y * a.sh[side] + (int64_t)x * a.sw[side];
+  const float* hist = a.hist + side * a.h_side + b * a.h_b + pix;
+  const int pos = a.n_frames + k;                              // window position of new slot k
+  const int e = pos < a.fl - 1 ? (int)a.hist_src[pos] : a.raw_first + pos - (a.fl - 1);
+  float d[3][1];
+  if (e >= 0) {
+    float in[3][1];
+    load_pixels<DT, 1>(a, side, off0 + e * a.sf[side], in);
+    convert_pixels<DT, 1>(a, in, d);
   } else {
-    dim3 grid((a.P + 255) / 256, 3 * a.batch, 2);
-    hipLaunchKernelGGL((k_fir_window<FL, 1>), grid, block, 0, s, a);
+    for (int p = 0; p < 3; ++p) d[p][0] = hist[p * a.h_plane + (int64_t)(-1 - e) * a.h_slot];
+  }
+  // write to the shadow copy (tmp) so that slots still to be read are not overwritten
+  float* dst = tmp + side * a.h_side + b * a.h_b + pix;
+  for (int p = 0; p < 3; ++p) dst[p * a.h_plane + (int64_t)k * a.h_slot] = d[p][0];
+}
+
+template <int DT, int FL>
+static void launch_fused(const FirArgs& a, hipStream_t s) {
+  constexpr int VMAX = FL <= 17 ? 2 : 1;
+  const int eb = dtype_bytes(a.dtype);
+  if (VMAX == 2 && a.P % 2 == 0 && can_vectorise(2, a.W, a.sb, a.sc, a.sf, a.sh, a.sw, a.src, eb)) {
+    dim3 grid((a.P / 2 + 255) / 256, a.batch, 2);
+    hipLaunchKernelGGL((k_fir_fused<DT, FL, 2>), grid, dim3(256), 0, s, a);
+  } else {
+    dim3 grid((a.P + 255) / 256, a.batch, 2);
+    hipLaunchKernelGGL((k_fir_fused<DT, FL, 1>), grid, dim3(256), 0, s, a);
   }
 }
 
-void launch_fir(const FirArgs& a, hipStream_t s) {
+template <int DT>
+static bool launch_dt(const FirArgs& a, hipStream_t s) {
   switch (a.fl) {
-    case 7: launch_window<7>(a, s); break;    // 24/25 fps... (N = ceil(fps/8)*2+1)
-    case 9: launch_window<9>(a, s); break;    // 30 fps
-    case 15: launch_window<15>(a, s); break;  // 50 fps
-    case 17: launch_window<17>(a, s); break;  // 60 fps
-    case 31: launch_window<31>(a, s); break;  // 120 fps
-    default: hipLaunchKernelGGL(k_fir_generic, dim3((a.P + 255) / 256, a.n_frames * a.batch, 2), dim3(256), 0, s, a); break;
+    case 7: launch_fused<DT, 7>(a, s); return true;     // 24 fps          (N = ceil(fps/8)*2+1)
+    case 9: launch_fused<DT, 9>(a, s); return true;     // 25, 30 fps
+    case 13: launch_fused<DT, 13>(a, s); return true;   // 48 fps
+    case 15: launch_fused<DT, 15>(a, s); return true;   // 50 fps
+    case 17: launch_fused<DT, 17>(a, s); return true;   // 60 fps
+    case 25: launch_fused<DT, 25>(a, s); return true;   // 90 fps
+    case 31: launch_fused<DT, 31>(a, s); return true;   // 120 fps
+    default: break;
+  }
+  hipLaunchKernelGGL(k_fir_generic<DT>, dim3((a.P + 255) / 256, a.n_frames * a.batch, 2), dim3(256), 0, s, a);
+  return false;
+}
+
+void launch_fir(const FirArgs& a, float* hist_shadow, hipStream_t s) {
+  bool fused;
+  switch (a.dtype) {
+    case CVVDP_U8: fused = launch_dt<CVVDP_U8>(a, s); break;
+    case CVVDP_U16: fused = launch_dt<CVVDP_U16>(a, s); break;
+    case CVVDP_F16: fused = launch_dt<CVVDP_F16>(a, s); break;
+    case CVVDP_F32: fused = launch_dt<CVVDP_F32>(a, s); break;
+    default: fused = launch_dt<CVVDP_F32_DKL>(a, s); break;
+  }
+  if (!fused && a.write_hist && a.fl > 1) {
+    dim3 grid((a.P + 255) / 256, (a.fl - 1) * a.batch, 2);
+    switch (a.dtype) {
+      case CVVDP_U8: hipLaunchKernelGGL(k_hist_generic<CVVDP_U8>, grid, dim3(256), 0, s, a, hist_shadow); break;
+      case CVVDP_U16: hipLaunchKernelGGL(k_hist_generic<CVVDP_U16>, grid, dim3(256), 0, s, a, hist_shadow); break;
+      case CVVDP_F16: hipLaunchKernelGGL(k_hist_generic<CVVDP_F16>, grid, dim3(256), 0, s, a, hist_shadow); break;
+      case CVVDP_F32: hipLaunchKernelGGL(k_hist_generic<CVVDP_F32>, grid, dim3(256), 0, s, a, hist_shadow); break;
+      default: hipLaunchKernelGGL(k_hist_generic<CVVDP_F32_DKL>, grid, dim3(256), 0, s, a, hist_shadow); break;
+    }
+    (void)hipMemcpyAsync(a.hist, hist_shadow, sizeof(float) * (size_t)2 * a.h_side, hipMemcpyDeviceToDevice, s);
   }
 }
 

@@ -235,18 +235,15 @@ class cvvdp(vq_metric):
         r = torch.cat(rs, dim=2).to(torch.float32).contiguous()
         return t, r, _capi.F32_DKL
 
-    def _put(self, t, r, code, first_slot, stream):
-        n = t.shape[2]
+    @staticmethod
+    def _strides(t, r):
         B = max(t.shape[0], r.shape[0])
-        st = list(t.stride())
-        sr = list(r.stride())
+        st, sr = list(t.stride()), list(r.stride())
         if t.shape[0] == 1 and B > 1:
-            st[0] = 0
+            st[0] = 0  # broadcast batch (video_source.py:247-252)
         if r.shape[0] == 1 and B > 1:
             sr[0] = 0
-        rc = _capi.lib().cvvdp_put_frames(self._handle, t.data_ptr(), r.data_ptr(), code, (ctypes.c_int64 * 5)(*st),
-                                          (ctypes.c_int64 * 5)(*sr), first_slot, n, stream)
-        _capi.check(self._handle, rc, "cvvdp_put_frames")
+        return (ctypes.c_int64 * 5)(*st), (ctypes.c_int64 * 5)(*sr)
 
     def _score_range(self, vs, first, count):
         """Q_per_ch [B, C, count, bands] (device tensor) of frames [first, first+count)."""
@@ -280,7 +277,6 @@ class cvvdp(vq_metric):
             nb = self._pick_block_frames(height * width, B, count, fl, nch)
             clip.filter_len, clip.block_frames = fl, nb
             self.last_block_frames = nb
-            clip.ring_slots = fl - 1 + max(nb, fl)
         rows = np.zeros((_capi.MAX_LEVELS, 4, _capi.CSF_NODES), dtype=f32)
         for bb in range(L):
             rows[bb] = self.csf_table.rows(rho_band[bb])
@@ -303,12 +299,14 @@ class cvvdp(vq_metric):
             heatmap[0, :, ff:ff + n] = buf.cpu()
 
         if is_image:
-            self._put(probe_t, probe_r, code, 0, stream)
+            st, sr = self._strides(probe_t, probe_r)
+            rc = lib.cvvdp_put_image(self._handle, probe_t.data_ptr(), probe_r.data_ptr(), code, st, sr, stream)
+            _capi.check(self._handle, rc, "cvvdp_put_image")
             _capi.check(self._handle, lib.cvvdp_process_image(self._handle, stream), "cvvdp_process_image")
             if self.do_heatmap:
                 fetch_heatmap(0, 1)
         else:
-            nb, slots = clip.block_frames, clip.ring_slots
+            nb = clip.block_frames
 
             def src_index(j):  # temporal padding before frame 0, cvvdp_metric.py:506-529
                 if j >= 0:
@@ -317,21 +315,27 @@ class cvvdp(vq_metric):
 
             if self.temp_padding not in ("replicate", "symmetric"):
                 raise RuntimeError(f'Unknown padding method "{self.temp_padding}"')
-            loaded_hi = None
             for ff in range(first, first + count, nb):
                 n = min(nb, first + count - ff)
-                window = [src_index(ff - (fl - 1) + k) for k in range(fl - 1 + n)]
-                lo, hi = min(window), max(window) + 1
-                if loaded_hi is None:
-                    loaded_hi = lo
-                if hi > loaded_hi:
-                    t, r, code = self._raw_block(vs, loaded_hi, hi)
-                    self._put(t, r, code, loaded_hi % slots, stream)
-                    loaded_hi = hi
-                win = (ctypes.c_int32 * len(window))(*[w % slots for w in window])
-                _capi.check(self._handle, lib.cvvdp_process_block(self._handle, win, n, ff - first, stream), "cvvdp_process_block")
+                if ff == first:
+                    # first block of the clip / shard: the fl-1 window positions before frame ff are real
+                    # halo frames or temporal padding; all of them are raw frames of the block handed in
+                    hist_frames = [src_index(ff - (fl - 1) + k) for k in range(fl - 1)]
+                    lo = min(hist_frames + [ff])
+                    hi = max(hist_frames + [ff + n - 1]) + 1
+                    hist = [f - lo for f in hist_frames]
+                else:
+                    # later blocks: the DKL tail of the previous block is still in the workspace
+                    lo, hi = ff, ff + n
+                    hist = [-1 - k for k in range(fl - 1)]
+                t, r, code = self._raw_block(vs, lo, hi)
+                st, sr = self._strides(t, r)
+                hist_c = (ctypes.c_int32 * max(len(hist), 1))(*hist)
+                rc = lib.cvvdp_process_block(self._handle, t.data_ptr(), r.data_ptr(), code, st, sr, ff - lo, hist_c, n, ff - first, stream)
+                _capi.check(self._handle, rc, "cvvdp_process_block")
                 if self.do_heatmap:
                     fetch_heatmap(ff - first, n)
+                del t, r  # stream-ordered: safe to release to the caching allocator once the kernels are queued
         Q = torch.empty((B, nch, count, L), dtype=torch.float32, device=self.device)
         _capi.check(self._handle, lib.cvvdp_get_q_per_ch(self._handle, Q.data_ptr(), stream), "cvvdp_get_q_per_ch")
         return Q, heatmap, rho_band

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CVVDP_ABI_VERSION 1
+#define CVVDP_ABI_VERSION 2
 #define CVVDP_MAX_FILTER_LEN 65 /* 0.25 s at up to 256 fps, cvvdp_metric.py:1059 */
 #define CVVDP_MAX_LEVELS 16
 #define CVVDP_MAX_WINDOW 256    /* filter_len - 1 + frames per block */
@@ -49,7 +49,7 @@ enum { CVVDP_EOTF_SRGB = 0, CVVDP_EOTF_PQ = 1, CVVDP_EOTF_HLG = 2, CVVDP_EOTF_LI
 /* heat-map modes, cvvdp_metric.py:117 */
 enum { CVVDP_HEATMAP_NONE = 0, CVVDP_HEATMAP_RAW = 1, CVVDP_HEATMAP_THRESHOLD = 2, CVVDP_HEATMAP_SUPRA = 3 };
 /* debug/inspection buffers inside the workspace (tests) */
-enum { CVVDP_BUF_RING = 0, CVVDP_BUF_GPYR = 1, CVVDP_BUF_DDUMP = 2, CVVDP_BUF_HEAT = 3, CVVDP_BUF_Q = 4 };
+enum { CVVDP_BUF_HIST = 0, CVVDP_BUF_GPYR = 1, CVVDP_BUF_DDUMP = 2, CVVDP_BUF_HEAT = 3, CVVDP_BUF_Q = 4 };
 
 /* Calibrated parameters + display photometry.  Host-side scalars of cvvdp_parameters.json as
  * loaded by cvvdp.load_config (cvvdp_metric.py:146-229) and of vvdp_display_photo_eotf
@@ -92,7 +92,6 @@ typedef struct cvvdp_clip {
   int32_t n_levels;             /* pyramid band count (lpyr.get_band_count()) */
   int32_t filter_len;           /* temporal filter length (video) */
   int32_t block_frames;         /* max frames per process_block call */
-  int32_t ring_slots;           /* physical slots of the DKL ring (video) */
   int32_t heatmap;              /* CVVDP_HEATMAP_* */
   int32_t debug_dump;           /* 1: keep per-pixel D of every band in the workspace (tests) */
   float taps[4 * CVVDP_MAX_FILTER_LEN];                             /* F[c][k], not flipped */
@@ -115,24 +114,30 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip);
 size_t cvvdp_workspace_bytes(const cvvdp_handle* h);
 int cvvdp_bind_workspace(cvvdp_handle* h, void* dev_workspace, size_t bytes);
 
-/* Frame supply + display model: video_source_array._get_frame (video_source.py:320-346),
+/* Image frame supply + display model: video_source_array._get_frame (video_source.py:320-346),
  * vvdp_display_photo_eotf.forward (display_model.py:333-365), linear_2_target_colorspace 'DKLd65'
- * (display_model.py:241-276).  Converts n_frames frames of test and reference (device arrays with
- * element strides in B,C,F,H,W order; a broadcast batch has stride 0) and stores DKL planes in ring
- * slots (first_slot + i) mod ring_slots (video) or directly as the 6 level-0 planes (image). */
-int cvvdp_put_frames(cvvdp_handle* h, const void* dev_test, const void* dev_ref, int32_t dtype,
-                     const int64_t strides_test[5], const int64_t strides_ref[5],
-                     int32_t first_slot, int32_t n_frames, void* stream);
+ * (display_model.py:241-276).  Converts the image pair (device arrays with element strides in
+ * B,C,F,H,W order; a broadcast batch has stride 0) into the 6 level-0 planes (cvvdp_metric.py:462-465). */
+int cvvdp_put_image(cvvdp_handle* h, const void* dev_test, const void* dev_ref, int32_t dtype,
+                    const int64_t strides_test[5], const int64_t strides_ref[5], void* stream);
 
-/* One block of frames: temporal FIR over the ring (cvvdp_metric.py:554-560), contrast pyramid
- * (lpyr_dec.py:364-414), CSF (csf.py:28-51), masking + pooling per band (cvvdp_metric.py:691-734).
- * window_slots[k] (host array, filter_len-1+n_frames entries) is the ring slot that holds sliding-
- * window position k, i.e. frame (first - (filter_len-1) + k) after temporal padding; this is how the
- * host mirror expresses replicate/symmetric padding (cvvdp_metric.py:506-529) without copying.
+/* One block of video frames, everything from samples to Q_per_ch: frame supply + display model as above,
+ * sliding-window temporal FIR (cvvdp_metric.py:453-560), contrast pyramid (lpyr_dec.py:364-414), CSF
+ * (csf.py:28-51), masking + pooling per band (cvvdp_metric.py:691-734).
+ *   dev_test/dev_ref  frame f of the handed-in arrays is "raw frame f" (element strides as above)
+ *   raw_first         raw index of the first scored frame; frames raw_first .. raw_first+n_frames-1 are scored
+ *   hist_src[k]       (host array, filter_len-1 entries) where sliding-window position k of the first scored
+ *                     frame comes from, i.e. frame (first - (filter_len-1) + k) after temporal padding:
+ *                     e >= 0: raw frame e of the handed-in arrays (replicate/symmetric padding of
+ *                     cvvdp_metric.py:506-529, or the real halo frames of a frame-range shard);
+ *                     e <  0: entry -1-e of the DKL tail kept from the previous call (replaces the ring +
+ *                     torch.roll of cvvdp_metric.py:538-539).
+ * The last filter_len-1 DKL frames are kept in the workspace for the next call.
  * Results land in Q_per_ch[:, :, q_frame_offset : q_frame_offset+n_frames, :]. */
-int cvvdp_process_block(cvvdp_handle* h, const int32_t* window_slots, int32_t n_frames,
-                        int32_t q_frame_offset, void* stream);
-/* Image variant (6 planes were written by cvvdp_put_frames), cvvdp_metric.py:462-465. */
+int cvvdp_process_block(cvvdp_handle* h, const void* dev_test, const void* dev_ref, int32_t dtype,
+                        const int64_t strides_test[5], const int64_t strides_ref[5], int32_t raw_first,
+                        const int32_t* hist_src, int32_t n_frames, int32_t q_frame_offset, void* stream);
+/* Image variant: pyramid, CSF, masking, pooling of the planes written by cvvdp_put_image. */
 int cvvdp_process_image(cvvdp_handle* h, void* stream);
 
 /* stats['Q_per_ch'] as fp32 [B, C, F, bands] (cvvdp_metric.py:388-392,419). */

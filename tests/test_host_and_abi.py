@@ -40,12 +40,13 @@ def test_abi_argument_validation_without_gpu():
     assert b"geometry" in lib.cvvdp_last_error(h)
     assert lib.cvvdp_workspace_bytes(h) == 0
     clip.batch, clip.channels, clip.height, clip.width, clip.is_video, clip.n_frames, clip.n_levels = 1, 3, 1080, 1920, 1, 64, 8
-    clip.filter_len, clip.block_frames, clip.ring_slots = 17, 16, 33
+    clip.filter_len, clip.block_frames = 17, 16
     assert lib.cvvdp_configure(h, ctypes.byref(clip)) == 0
     need = lib.cvvdp_workspace_bytes(h)
     P0 = 1080 * 1920
-    assert need > (6 * 33 + 8 * 16 * 1.33) * P0 * 4 and need < (6 * 33 + 8 * 16 * 1.35) * P0 * 4 + (1 << 22)
-    assert lib.cvvdp_process_block(h, None, 1, 0, None) == -2  # no workspace bound
+    # DKL tail (6 planes x 16 frames) + 8 planes x 16 frames x 4/3 pyramid
+    assert need > (6 * 16 + 8 * 16 * 1.33) * P0 * 4 and need < (6 * 16 + 8 * 16 * 1.35) * P0 * 4 + (1 << 22)
+    assert lib.cvvdp_process_block(h, None, None, 3, None, None, 0, None, 1, 0, None) == -2  # no workspace bound
     lib.cvvdp_destroy(h)
 
 

@@ -7,12 +7,18 @@
 
 namespace cvvdp {
 
+// Constant divisions are multiplications by the rounded reciprocal (an IEEE fp32 divide is a ~10
+// instruction sequence on gfx950 and these run once per sample); the result differs from x/255 by at
+// most 1 ulp, far inside the parity tolerance.
+constexpr float kInv255 = 1.0f / 255.0f;
+constexpr float kInv65535 = 1.0f / 65535.0f;
+
 template <int DT>
 __device__ __forceinline__ float load_sample(const void* base, int64_t off) {
   if constexpr (DT == CVVDP_U8) {
-    return (float)reinterpret_cast<const uint8_t*>(base)[off] / 255.0f;
+    return (float)reinterpret_cast<const uint8_t*>(base)[off] * kInv255;
   } else if constexpr (DT == CVVDP_U16) {
-    return (float)reinterpret_cast<const uint16_t*>(base)[off] / 65535.0f;
+    return (float)reinterpret_cast<const uint16_t*>(base)[off] * kInv65535;
   } else if constexpr (DT == CVVDP_F16) {
     return __half2float(reinterpret_cast<const __half*>(base)[off]);
   } else {
@@ -23,8 +29,8 @@ __device__ __forceinline__ float load_sample(const void* base, int64_t off) {
 __device__ __forceinline__ float srgb2lin(float p) {
   // display_model.py:78-80
   // x^2.4 = x^2 * x^0.4: the SFU part has |0.4*log2 x| <= 1.4, so the result stays within ~2 ulp
-  const float x = (p + 0.055f) / 1.055f;
-  return p > 0.04045f ? x * x * fast_pow(x, 0.4f) : p / 12.92f;
+  const float x = (p + 0.055f) * (1.0f / 1.055f);
+  return p > 0.04045f ? x * x * fast_pow(x, 0.4f) : p * (1.0f / 12.92f);
 }
 
 __device__ __forceinline__ float pq2lin(float v) {
@@ -32,7 +38,7 @@ __device__ __forceinline__ float pq2lin(float v) {
   const float n = 0.15930175781250000f, m = 78.843750000000000f;
   const float c1 = 0.83593750000000000f, c2 = 18.851562500000000f, c3 = 18.687500000000000f;
   float t = fast_pow(v, 1.0f / m);
-  return 10000.0f * fast_pow(fmaxf(t - c1, 0.0f) / (c2 - c3 * t), 1.0f / n);
+  return 10000.0f * fast_pow(fmaxf(t - c1, 0.0f) * fast_rcp(c2 - c3 * t), 1.0f / n);
 }
 
 __device__ __forceinline__ float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
@@ -64,7 +70,7 @@ __device__ __forceinline__ void pixel_to_dkl(const DisplayArgs& a, float (&v)[3]
     const float hc = a.hlg_c;  // 0.5 - a*ln(4a), evaluated in double on the host like the reference
     float s[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) s[c] = v[c] <= 0.5f ? v[c] * v[c] / 3.0f : (expf((v[c] - hc) / ha) + hb) / 12.0f;
+    for (int c = 0; c < 3; ++c) s[c] = v[c] <= 0.5f ? v[c] * v[c] * (1.0f / 3.0f) : (fast_exp2((v[c] - hc) * (1.4426950408889634f / ha)) + hb) * (1.0f / 12.0f);
     const float Ys = 0.2627f * s[0] + 0.6780f * s[1] + 0.0593f * s[2];
     const float gain = fast_pow(Ys, a.gamma - 1.0f);
 #pragma unroll
@@ -94,18 +100,18 @@ __device__ __forceinline__ void load_run(const void* base, int64_t off, float (&
   } else if constexpr (DT == CVVDP_U8) {
     if constexpr (V == 2) {
       const uchar2 q = *reinterpret_cast<const uchar2*>(reinterpret_cast<const uint8_t*>(base) + off);
-      out[0] = (float)q.x / 255.0f; out[1] = (float)q.y / 255.0f;
+      out[0] = (float)q.x * kInv255; out[1] = (float)q.y * kInv255;
     } else {
       const uchar4 q = *reinterpret_cast<const uchar4*>(reinterpret_cast<const uint8_t*>(base) + off);
-      out[0] = (float)q.x / 255.0f; out[1] = (float)q.y / 255.0f; out[2] = (float)q.z / 255.0f; out[3] = (float)q.w / 255.0f;
+      out[0] = (float)q.x * kInv255; out[1] = (float)q.y * kInv255; out[2] = (float)q.z * kInv255; out[3] = (float)q.w * kInv255;
     }
   } else if constexpr (DT == CVVDP_U16) {
     if constexpr (V == 2) {
       const ushort2 q = *reinterpret_cast<const ushort2*>(reinterpret_cast<const uint16_t*>(base) + off);
-      out[0] = (float)q.x / 65535.0f; out[1] = (float)q.y / 65535.0f;
+      out[0] = (float)q.x * kInv65535; out[1] = (float)q.y * kInv65535;
     } else {
       const ushort4 q = *reinterpret_cast<const ushort4*>(reinterpret_cast<const uint16_t*>(base) + off);
-      out[0] = (float)q.x / 65535.0f; out[1] = (float)q.y / 65535.0f; out[2] = (float)q.z / 65535.0f; out[3] = (float)q.w / 65535.0f;
+      out[0] = (float)q.x * kInv65535; out[1] = (float)q.y * kInv65535; out[2] = (float)q.z * kInv65535; out[3] = (float)q.w * kInv65535;
     }
   } else if constexpr (DT == CVVDP_F16) {
     const __half2* p = reinterpret_cast<const __half2*>(reinterpret_cast<const __half*>(base) + off);

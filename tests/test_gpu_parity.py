@@ -129,7 +129,8 @@ def test_device_resident_and_strided_inputs():
     tf = (torch.tensor(t).float() / 255).cuda()
     rf = (torch.tensor(r).float() / 255).cuda()
     jod2, s2 = m.predict(tf, rf, dim_order="FHWC", frames_per_second=60)
-    np.testing.assert_allclose(s2["Q_per_ch"], s0["Q_per_ch"], rtol=1e-5, atol=1e-7)
+    # u8 samples are scaled by the rounded reciprocal of 255 on the GPU (<= 1 ulp from x/255)
+    np.testing.assert_allclose(s2["Q_per_ch"], s0["Q_per_ch"], rtol=1e-4, atol=1e-6)
 
 
 def test_custom_video_source_slow_path():

@@ -14,41 +14,28 @@
 //     expressed by the host as "history entry k = raw frame index e" and converted in the prologue.
 // The next frame's samples are loaded before the current frame's FMAs (software prefetch).
 #include "photometry_dev.h"
-#include <cstdlib>
 
 namespace cvvdp {
 
-// The sample type is a (wave-uniform) run-time switch here, not a template parameter: the FIR body is
-// large (one fully unrolled copy per window rotation) and must not be multiplied by five input formats.
-template <int V>
-__device__ __forceinline__ void load_any(int dtype, const void* src, int64_t off, float (&out)[V]) {
-  switch (dtype) {
-    case CVVDP_U8: load_run<CVVDP_U8, V>(src, off, out); break;
-    case CVVDP_U16: load_run<CVVDP_U16, V>(src, off, out); break;
-    case CVVDP_F16: load_run<CVVDP_F16, V>(src, off, out); break;
-    default: load_run<CVVDP_F32, V>(src, off, out); break;
-  }
-}
-
-template <int V>
+template <int DT, int V>
 __device__ __forceinline__ void load_pixels(const FirArgs& a, int side, int64_t off, float (&in)[3][V]) {
   const void* src = a.src[side];
   if (a.dm.channels == 3) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) load_any<V>(a.dtype, src, off + c * a.sc[side], in[c]);
+    for (int c = 0; c < 3; ++c) load_run<DT, V>(src, off + c * a.sc[side], in[c]);
   } else {
-    load_any<V>(a.dtype, src, off, in[0]);
+    load_run<DT, V>(src, off, in[0]);
 #pragma unroll
     for (int i = 0; i < V; ++i) in[1][i] = in[2][i] = in[0][i];
   }
 }
 
-template <int V>
+template <int DT, int V>
 __device__ __forceinline__ void convert_pixels(const FirArgs& a, const float (&in)[3][V], float (&dkl)[3][V]) {
 #pragma unroll
   for (int i = 0; i < V; ++i) {
     float v[3] = {in[0][i], in[1][i], in[2][i]}, o[3];
-    if (a.dtype == CVVDP_F32_DKL) {
+    if constexpr (DT == CVVDP_F32_DKL) {
       o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
     } else {
       pixel_to_dkl(a.dm, v, o);
@@ -70,40 +57,7 @@ __device__ __forceinline__ void load_f32_run(const float* p, float (&v)[V]) {
   else { const float4 q = *reinterpret_cast<const float4*>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
 }
 
-// One output frame with the newest sample stored in slot S: window position k lives in slot (S+1+k) % FL.
-template <int FL, int V, int S>
-__device__ __forceinline__ void fir_step(float (&w)[3][FL][V], const float (&d)[3][V], const FirArgs& a, float* out, int side) {
-#pragma unroll
-  for (int p = 0; p < 3; ++p)
-#pragma unroll
-    for (int i = 0; i < V; ++i) w[p][S][i] = d[p][i];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {     // Y-sust, RG, YV, Y-trans (window of plane 0 again), cvvdp_metric.py:554-560
-    const int p = (c == 3) ? 0 : c;
-    float acc[V];
-#pragma unroll
-    for (int i = 0; i < V; ++i) acc[i] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < FL; ++k)
-#pragma unroll
-      for (int i = 0; i < V; ++i) acc[i] += w[p][(S + 1 + k) % FL][i] * a.taps[c * CVVDP_MAX_FILTER_LEN + k];
-    store_run<V>(out + (int64_t)(2 * c + side) * a.o_plane, acc);
-  }
-}
-// history tail = window positions 1..FL-1 in time order when the oldest entry sits in slot S
-template <int FL, int V, int S>
-__device__ __forceinline__ void hist_step(float (&w)[3][FL][V], const FirArgs& a, float* hist) {
-#pragma unroll
-  for (int k = 0; k < FL - 1; ++k)
-#pragma unroll
-    for (int p = 0; p < 3; ++p) store_run<V>(hist + p * a.h_plane + (int64_t)k * a.h_slot, w[p][(S + 1 + k) % FL]);
-}
-#define CVVDP_ROT_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
-// filter lengths whose time loop is unrolled by FL (window rotation with static register indices, no
-// per-frame shifting): the two common frame-rate classes.  Others shift (code size / compile time).
-template <int FL, int V> constexpr bool kRotate = (V == 1) && (FL == 17 || FL == 9);   // V == 2 rotated needs > 200 VGPRs: slower
-
-template <int FL, int V>
+template <int DT, int FL, int V>
 __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
   const int pix = (blockIdx.x * 256 + threadIdx.x) * V;
   if (pix >= a.P) return;
@@ -120,8 +74,8 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
     const int e = a.hist_src[k];
     if (e >= 0) {       // raw frame e of the block handed in by the host
       float in[3][V], d[3][V];
-      load_pixels<V>(a, side, off0 + e * sf, in);
-      convert_pixels<V>(a, in, d);
+      load_pixels<DT, V>(a, side, off0 + e * sf, in);
+      convert_pixels<DT, V>(a, in, d);
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -139,53 +93,50 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
   float pf[PF][3][V];
 #pragma unroll
   for (int q = 0; q < PF; ++q)
-    if (q < a.n_frames) load_pixels<V>(a, side, off0 + (int64_t)(a.raw_first + q) * sf, pf[q]);
-  auto advance = [&](float (&d)[3][V], int fi) {     // convert the oldest prefetched frame, refill the queue
-    convert_pixels<V>(a, pf[0], d);
+    if (q < a.n_frames) load_pixels<DT, V>(a, side, off0 + (int64_t)(a.raw_first + q) * sf, pf[q]);
+  for (int fi = 0; fi < a.n_frames; ++fi) {
+    float d[3][V];
+    convert_pixels<DT, V>(a, pf[0], d);
 #pragma unroll
     for (int q = 0; q + 1 < PF; ++q)
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int i = 0; i < V; ++i) pf[q][p][i] = pf[q + 1][p][i];
-    if (fi + PF < a.n_frames) load_pixels<V>(a, side, off0 + (int64_t)(a.raw_first + fi + PF) * sf, pf[PF - 1]);
-  };
-  int slot = 0;   // slot of the OLDEST window entry = the one the next frame overwrites (prologue filled 1..FL-1)
-  if constexpr (kRotate<FL, V>) {
-    int fi = 0;
-    while (fi < a.n_frames) {
-#define CVVDP_FIR_STEP(S) if constexpr (S < FL) { if (fi < a.n_frames) { float d[3][V]; advance(d, fi); \
-        fir_step<FL, V, S>(w, d, a, out + (int64_t)fi * o_item, side); ++fi; } }
-      CVVDP_ROT_CASES(CVVDP_FIR_STEP)
-#undef CVVDP_FIR_STEP
+    if (fi + PF < a.n_frames) load_pixels<DT, V>(a, side, off0 + (int64_t)(a.raw_first + fi + PF) * sf, pf[PF - 1]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int k = 0; k < FL - 1; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) w[p][k][i] = w[p][k + 1][i];
+#pragma unroll
+      for (int i = 0; i < V; ++i) w[p][FL - 1][i] = d[p][i];
     }
-    slot = a.n_frames % FL;
-  } else {
-    for (int fi = 0; fi < a.n_frames; ++fi) {
-      float d[3][V];
-      advance(d, fi);
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+    for (int c = 0; c < 4; ++c) {     // Y-sust, RG, YV, Y-trans (window of plane 0 again), cvvdp_metric.py:554-560
+      const int p = (c == 3) ? 0 : c;
+      float acc[V];
 #pragma unroll
-        for (int k = 0; k < FL - 1; ++k)
+      for (int i = 0; i < V; ++i) acc[i] = 0.0f;
 #pragma unroll
-          for (int i = 0; i < V; ++i) w[p][k][i] = w[p][k + 1][i];
-      fir_step<FL, V, FL - 1>(w, d, a, out + (int64_t)fi * o_item, side);   // window position k stays at index k
+      for (int k = 0; k < FL; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] += w[p][k][i] * a.taps[c * CVVDP_MAX_FILTER_LEN + k];
+      store_run<V>(out + (int64_t)(2 * c + side) * a.o_plane + (int64_t)fi * o_item, acc);
     }
   }
   // ---- epilogue: the last FL-1 frames become the next block's history
   if (a.write_hist) {
-    if constexpr (kRotate<FL, V>) {
-#define CVVDP_HIST_CASE(S) case S: if constexpr (S < FL) hist_step<FL, V, S>(w, a, hist); break;
-      switch (slot) { CVVDP_ROT_CASES(CVVDP_HIST_CASE) default: break; }
-#undef CVVDP_HIST_CASE
-    } else {
-      hist_step<FL, V, 0>(w, a, hist);   // positions 1..FL-1 = indices 1..FL-1
-    }
+#pragma unroll
+    for (int k = 0; k < FL - 1; ++k)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) store_run<V>(hist + p * a.h_plane + (int64_t)k * a.h_slot, w[p][k + 1]);
   }
 }
 
 // Any filter length (odd frame rates): no register window; every tap re-reads and re-converts its frame.
+template <int DT>
 __global__ __launch_bounds__(256) void k_fir_generic(FirArgs a) {
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= a.P) return;
@@ -201,8 +152,8 @@ __global__ __launch_bounds__(256) void k_fir_generic(FirArgs a) {
     const int e = pos < a.fl - 1 ? (int)a.hist_src[pos] : a.raw_first + pos - (a.fl - 1);
     if (e >= 0) {
       float in[3][1];
-      load_pixels<1>(a, side, off0 + e * a.sf[side], in);
-      convert_pixels<1>(a, in, d);
+      load_pixels<DT, 1>(a, side, off0 + e * a.sf[side], in);
+      convert_pixels<DT, 1>(a, in, d);
     } else {
       for (int p = 0; p < 3; ++p) d[p][0] = hist[p * a.h_plane + (int64_t)(-1 - e) * a.h_slot];
     }
@@ -212,6 +163,7 @@ __global__ __launch_bounds__(256) void k_fir_generic(FirArgs a) {
 }
 
 // tail of the block -> history, for the generic path (the fused kernel does this itself)
+template <int DT>
 __global__ __launch_bounds__(256) void k_hist_generic(FirArgs a, float* tmp) {
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= a.P) return;
@@ -224,8 +176,8 @@ __global__ __launch_bounds__(256) void k_hist_generic(FirArgs a, float* tmp) {
   float d[3][1];
   if (e >= 0) {
     float in[3][1];
-    load_pixels<1>(a, side, off0 + e * a.sf[side], in);
-    convert_pixels<1>(a, in, d);
+    load_pixels<DT, 1>(a, side, off0 + e * a.sf[side], in);
+    convert_pixels<DT, 1>(a, in, d);
   } else {
     for (int p = 0; p < 3; ++p) d[p][0] = hist[p * a.h_plane + (int64_t)(-1 - e) * a.h_slot];
   }
@@ -234,35 +186,53 @@ __global__ __launch_bounds__(256) void k_hist_generic(FirArgs a, float* tmp) {
   for (int p = 0; p < 3; ++p) dst[p * a.h_plane + (int64_t)k * a.h_slot] = d[p][0];
 }
 
-template <int FL>
+template <int DT, int FL>
 static void launch_fused(const FirArgs& a, hipStream_t s) {
   constexpr int VMAX = FL <= 17 ? 2 : 1;
   const int eb = dtype_bytes(a.dtype);
-  static const int vcap = getenv("CVVDP_FIR_V") ? atoi(getenv("CVVDP_FIR_V")) : 2;   // tuning hook
-  if (VMAX == 2 && vcap >= 2 && a.P % 2 == 0 && can_vectorise(2, a.W, a.sb, a.sc, a.sf, a.sh, a.sw, a.src, eb)) {
+  if (VMAX == 2 && a.P % 2 == 0 && can_vectorise(2, a.W, a.sb, a.sc, a.sf, a.sh, a.sw, a.src, eb)) {
     dim3 grid((a.P / 2 + 255) / 256, a.batch, 2);
-    hipLaunchKernelGGL((k_fir_fused<FL, VMAX>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_fir_fused<DT, FL, 2>), grid, dim3(256), 0, s, a);
   } else {
     dim3 grid((a.P + 255) / 256, a.batch, 2);
-    hipLaunchKernelGGL((k_fir_fused<FL, 1>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_fir_fused<DT, FL, 1>), grid, dim3(256), 0, s, a);
   }
 }
 
-void launch_fir(const FirArgs& a, float* hist_shadow, hipStream_t s) {
+template <int DT>
+static bool launch_dt(const FirArgs& a, hipStream_t s) {
   switch (a.fl) {
-    case 7: launch_fused<7>(a, s); return;     // 24 fps          (N = ceil(fps/8)*2+1)
-    case 9: launch_fused<9>(a, s); return;     // 25, 30 fps
-    case 13: launch_fused<13>(a, s); return;   // 48 fps
-    case 15: launch_fused<15>(a, s); return;   // 50 fps
-    case 17: launch_fused<17>(a, s); return;   // 60 fps
-    case 25: launch_fused<25>(a, s); return;   // 90 fps
-    case 31: launch_fused<31>(a, s); return;   // 120 fps
+    case 7: launch_fused<DT, 7>(a, s); return true;     // 24 fps          (N = ceil(fps/8)*2+1)
+    case 9: launch_fused<DT, 9>(a, s); return true;     // 25, 30 fps
+    case 13: launch_fused<DT, 13>(a, s); return true;   // 48 fps
+    case 15: launch_fused<DT, 15>(a, s); return true;   // 50 fps
+    case 17: launch_fused<DT, 17>(a, s); return true;   // 60 fps
+    case 25: launch_fused<DT, 25>(a, s); return true;   // 90 fps
+    case 31: launch_fused<DT, 31>(a, s); return true;   // 120 fps
     default: break;
   }
-  hipLaunchKernelGGL(k_fir_generic, dim3((a.P + 255) / 256, a.n_frames * a.batch, 2), dim3(256), 0, s, a);
-  if (a.write_hist && a.fl > 1) {
+  hipLaunchKernelGGL(k_fir_generic<DT>, dim3((a.P + 255) / 256, a.n_frames * a.batch, 2), dim3(256), 0, s, a);
+  return false;
+}
+
+void launch_fir(const FirArgs& a, float* hist_shadow, hipStream_t s) {
+  bool fused;
+  switch (a.dtype) {
+    case CVVDP_U8: fused = launch_dt<CVVDP_U8>(a, s); break;
+    case CVVDP_U16: fused = launch_dt<CVVDP_U16>(a, s); break;
+    case CVVDP_F16: fused = launch_dt<CVVDP_F16>(a, s); break;
+    case CVVDP_F32: fused = launch_dt<CVVDP_F32>(a, s); break;
+    default: fused = launch_dt<CVVDP_F32_DKL>(a, s); break;
+  }
+  if (!fused && a.write_hist && a.fl > 1) {
     dim3 grid((a.P + 255) / 256, (a.fl - 1) * a.batch, 2);
-    hipLaunchKernelGGL(k_hist_generic, grid, dim3(256), 0, s, a, hist_shadow);
+    switch (a.dtype) {
+      case CVVDP_U8: hipLaunchKernelGGL(k_hist_generic<CVVDP_U8>, grid, dim3(256), 0, s, a, hist_shadow); break;
+      case CVVDP_U16: hipLaunchKernelGGL(k_hist_generic<CVVDP_U16>, grid, dim3(256), 0, s, a, hist_shadow); break;
+      case CVVDP_F16: hipLaunchKernelGGL(k_hist_generic<CVVDP_F16>, grid, dim3(256), 0, s, a, hist_shadow); break;
+      case CVVDP_F32: hipLaunchKernelGGL(k_hist_generic<CVVDP_F32>, grid, dim3(256), 0, s, a, hist_shadow); break;
+      default: hipLaunchKernelGGL(k_hist_generic<CVVDP_F32_DKL>, grid, dim3(256), 0, s, a, hist_shadow); break;
+    }
     (void)hipMemcpyAsync(a.hist, hist_shadow, sizeof(float) * (size_t)2 * a.h_side, hipMemcpyDeviceToDevice, s);
   }
 }

@@ -20,16 +20,17 @@ def main(path):
         print("%-92s %7d %12.3f %11.1f %11.1f %11.1f %6.2f %5s %5s %7s %s..%s" % (nm, c, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total, vg, sg, lds, g0, g1))
     print("# total GPU kernel time: %.3f ms" % (total / 1e6))
     try:
-        pm = cur.execute("select k.name, p.counter_name, count(*), sum(p.counter_value) from pmc_events p join kernels k on p.event_id = k.event_id "
-                         "group by k.name, p.counter_name order by k.name").fetchall()
+        pm = cur.execute("select p.name, k.grid_x*k.grid_y*k.grid_z/(k.workgroup_x*k.workgroup_y*k.workgroup_z) as wg, p.counter_name, "
+                         "count(distinct p.dispatch_id), sum(p.counter_value) from pmc_events p join kernels k on p.dispatch_id = k.dispatch_id "
+                         "group by p.name, wg, p.counter_name order by sum(p.counter_value) desc").fetchall()
     except sqlite3.Error as e:
         pm = []
     if pm:
         print("\n# PMC counters (sum over dispatches; per-dispatch = sum / dispatches)")
-        print("%-92s %-24s %9s %18s %18s" % ("kernel", "counter", "dispatch", "sum", "per_dispatch"))
-        for n, cn, c, v in pm:
-            nm = n if len(n) <= 92 else n[:89] + "..."
-            print("%-92s %-24s %9d %18.1f %18.1f" % (nm, cn, c, v, v / c))
+        print("%-72s %10s %-20s %9s %18s %18s" % ("kernel", "workgroups", "counter", "dispatch", "sum", "per_dispatch"))
+        for n, wg, cn, c, v in pm:
+            nm = n if len(n) <= 72 else n[:69] + "..."
+            print("%-72s %10d %-20s %9d %18.1f %18.1f" % (nm, wg, cn, c, v, v / c))
 
 
 if __name__ == "__main__":

@@ -62,7 +62,7 @@ __device__ __forceinline__ int refl(int i, int n) {
 template <int NCH>
 __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   constexpr int NP = 2 * NCH;
-  __shared__ __attribute__((aligned(16))) float s_ve[NP][B4_VE];
+  __shared__ __attribute__((aligned(16))) float2 s_ve[NP][B4_VE / 2];   // float2 rows: guaranteed 8-byte aligned ds_read_b64
   __shared__ __attribute__((aligned(16))) float s_m[NCH][256];
   __shared__ __attribute__((aligned(16))) float s_q[NCH][256];
   __shared__ __attribute__((aligned(16))) float s_d[B4_R + 1][NCH][256];
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
 
   for (int i = t; i < NCH * CVVDP_CSF_NODES; i += 64 * NCH) {
     const int cc = i / CVVDP_CSF_NODES;
-    // log2-domain CSF row with the constant gains folded in: S*ch_gain = 2^(lut*log2(10) + log2(sens_mul*ch_gain))
-    s_lut[cc][i - cc * CVVDP_CSF_NODES] = a.lut[i] * kLog2_10 + fast_log2(a.sens_mul * a.ch_gain[cc]);
+    // log2-domain CSF row with the constant gains folded in: S*ch_gain*band_mul = 2^(lut*log2(10) + log2(sens_mul*ch_gain*band_mul))
+    s_lut[cc][i - cc * CVVDP_CSF_NODES] = a.lut[i] * kLog2_10 + fast_log2(a.sens_mul * a.ch_gain[cc] * a.band_mul);
   }
   const float e0 = a.kx[0], e1 = a.kx[1], eo = a.kx[2];
   const float ind_scale = (float)(CVVDP_CSF_NODES - 1) / (a.logL_last - a.logL_first);
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   // global loads are issued a whole row-iteration before their values are needed
   const int cx = min(max(vcx, 0), Wc - 4);
   const bool clampL = vcx < 0, clampR = vcx >= Wc;
+  const bool edge_block = cb < 0 || cb + 128 > Wc;   // block-uniform: only edge strips pay for the replicate selects
   float4 cA, cB, cC;    // coarse rows my-1, my, my+1 (clamped) of the chunk
   auto stage1_load = [&](int rr) {
     const int my = rr >> 1;
@@ -113,8 +114,10 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   };
   auto stage1_finish = [&](int rr) {
     auto fix = [&](const float4& q) -> f4 {
-      if (clampL) return f4{{q.x, q.x, q.x, q.x}};
-      if (clampR) return f4{{q.w, q.w, q.w, q.w}};
+      if (edge_block) {
+        if (clampL) return f4{{q.x, q.x, q.x, q.x}};
+        if (clampR) return f4{{q.w, q.w, q.w, q.w}};
+      }
       return f4{{q.x, q.y, q.z, q.w}};
     };
     const f4 m0 = fix(cA), m1 = fix(cB), m2 = fix(cC);
@@ -126,15 +129,15 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = m0.v[i] * e0 + m1.v[i] * e1 + m2.v[i] * e0;
     }
-    lds_write4(&s_ve[vp][4 + 4 * vch], o);
+    lds_write4(reinterpret_cast<float*>(&s_ve[vp][2 + 2 * vch]), o);
   };
 
   // horizontal half of the expand for this lane's 4 columns from 4 coarse values (lpyr_dec.py:234-237)
-  auto expand4 = [&](const float* row, float (&ex)[4]) {
+  auto expand4 = [&](const float2* row, float (&ex)[4]) {
     // coarse cb+2j-1 .. cb+2j+2 live at elements 2j+3 .. 2j+6: three aligned ds_read_b64 (conflict-free)
-    const float2 p0 = *reinterpret_cast<const float2*>(row + 2 * j + 2);
-    const float2 p1 = *reinterpret_cast<const float2*>(row + 2 * j + 4);
-    const float2 p2 = *reinterpret_cast<const float2*>(row + 2 * j + 6);
+    const float2 p0 = row[j + 1];
+    const float2 p1 = row[j + 2];
+    const float2 p2 = row[j + 3];
     const float A = p0.y, B = p1.x, C = p1.y, D = p2.x;
     ex[0] = A * e0 + B * e1 + C * e0;
     ex[1] = B * eo + C * eo;
@@ -189,14 +192,14 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     float m[4] = {0.0f, 0.0f, 0.0f, 0.0f}, d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (in_img) {
       float exT[4], exR[4], eyT[4], eyR[4];
-      expand4(&s_ve[2 * c][0], exT);
-      expand4(&s_ve[2 * c + 1][0], exR);
+      expand4(s_ve[2 * c], exT);
+      expand4(s_ve[2 * c + 1], exR);
       if (c == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { eyT[i] = exT[i]; eyR[i] = exR[i]; }
       } else {
-        expand4(&s_ve[0][0], eyT);
-        expand4(&s_ve[1][0], eyR);
+        expand4(s_ve[0], eyT);
+        expand4(s_ve[1], eyR);
       }
       const float gt[4] = {pT.x, pT.y, pT.z, pT.w}, gr[4] = {pR.x, pR.y, pR.z, pR.w};
 #pragma unroll
@@ -210,8 +213,8 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
         const int i1 = min(i0 + 1, CVVDP_CSF_NODES - 1);
         const float l0 = s_lut[c][i0], l1 = s_lut[c][i1];
         const float S = fast_exp2(l0 + (l1 - l0) * fr);                        // csf.py:49, cvvdp_metric.py:709,:836
-        const float ct = fminf((gt[i] - exT[i]) * rLt, 1000.0f) * a.band_mul;  // lpyr_dec.py:402, :66
-        const float cr = fminf((gr[i] - exR[i]) * rLr, 1000.0f) * a.band_mul;
+        const float ct = fminf((gt[i] - exT[i]) * rLt, 1000.0f);               // lpyr_dec.py:402 (band gain :66 is in S)
+        const float cr = fminf((gr[i] - exR[i]) * rLr, 1000.0f);
         const float Tp = ct * S, Rp = cr * S;
         m[i] = fminf(fabsf(Tp), fabsf(Rp));                                    // cvvdp_metric.py:845
         d[i] = fabsf(Tp - Rp);

@@ -14,6 +14,7 @@
 //     expressed by the host as "history entry k = raw frame index e" and converted in the prologue.
 // The next frame's samples are loaded before the current frame's FMAs (software prefetch).
 #include "photometry_dev.h"
+#include <cstdlib>
 
 namespace cvvdp {
 
@@ -67,8 +68,13 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
   const int64_t sf = a.sf[side];
   float* hist = a.hist + side * a.h_side + b * a.h_b + pix;
 
-  float w[3][FL][V];
-  // ---- prologue: window positions 0..FL-2 (history / temporal padding) go to w[.][1..FL-1]
+  // Window of FL + U - 1 entries: a chunk of U frames is appended at static positions FL-1 .. FL+U-2, the U
+  // outputs read statically shifted sub-windows, and the window is shifted by U once per chunk (the
+  // per-frame shift of FL*3*V registers was a third of this kernel's VALU work).
+  constexpr int U = (FL <= 17 && V == 1) ? 4 : 1;   // measured on 4K/60: V=1,U=4 8.4 ms; V=2,U=1 9.0 ms; V=2,U=4 12 ms (212 VGPRs)
+  constexpr int WL = FL + U - 1;
+  float w[3][WL][V];
+  // ---- prologue: window positions 0..FL-2 (history / temporal padding)
 #pragma unroll
   for (int k = 0; k < FL - 1; ++k) {
     const int e = a.hist_src[k];
@@ -79,10 +85,10 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int i = 0; i < V; ++i) w[p][k + 1][i] = d[p][i];
+        for (int i = 0; i < V; ++i) w[p][k][i] = d[p][i];
     } else {            // slot -1-e of the previous block's tail
 #pragma unroll
-      for (int p = 0; p < 3; ++p) load_f32_run<V>(hist + p * a.h_plane + (int64_t)(-1 - e) * a.h_slot, w[p][k + 1]);
+      for (int p = 0; p < 3; ++p) load_f32_run<V>(hist + p * a.h_plane + (int64_t)(-1 - e) * a.h_slot, w[p][k]);
     }
   }
   float* out = a.out + (int64_t)b * a.P + pix;
@@ -94,44 +100,60 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
 #pragma unroll
   for (int q = 0; q < PF; ++q)
     if (q < a.n_frames) load_pixels<DT, V>(a, side, off0 + (int64_t)(a.raw_first + q) * sf, pf[q]);
-  for (int fi = 0; fi < a.n_frames; ++fi) {
-    float d[3][V];
-    convert_pixels<DT, V>(a, pf[0], d);
+  for (int f0 = 0; f0 < a.n_frames; f0 += U) {
 #pragma unroll
-    for (int q = 0; q + 1 < PF; ++q)
+    for (int u = 0; u < U; ++u) {
+      const int fi = f0 + u;
+      if (fi < a.n_frames) {     // uniform
+        float d[3][V];
+        convert_pixels<DT, V>(a, pf[0], d);
+#pragma unroll
+        for (int q = 0; q + 1 < PF; ++q)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < V; ++i) pf[q][p][i] = pf[q + 1][p][i];
+        if (fi + PF < a.n_frames) load_pixels<DT, V>(a, side, off0 + (int64_t)(a.raw_first + fi + PF) * sf, pf[PF - 1]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int i = 0; i < V; ++i) w[p][FL - 1 + u][i] = d[p][i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {     // Y-sust, RG, YV, Y-trans (window of plane 0 again), cvvdp_metric.py:554-560
+          const int p = (c == 3) ? 0 : c;
+          float acc[V];
+#pragma unroll
+          for (int i = 0; i < V; ++i) acc[i] = 0.0f;
+#pragma unroll
+          for (int k = 0; k < FL; ++k)
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i] += w[p][u + k][i] * a.taps[c * CVVDP_MAX_FILTER_LEN + k];
+          store_run<V>(out + (int64_t)(2 * c + side) * a.o_plane + (int64_t)fi * o_item, acc);
+        }
+      }
+    }
+    if (f0 + U < a.n_frames) {   // more chunks follow: drop the U oldest entries
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int i = 0; i < V; ++i) pf[q][p][i] = pf[q + 1][p][i];
-    if (fi + PF < a.n_frames) load_pixels<DT, V>(a, side, off0 + (int64_t)(a.raw_first + fi + PF) * sf, pf[PF - 1]);
+        for (int k = 0; k < FL - 1; ++k)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-#pragma unroll
-      for (int k = 0; k < FL - 1; ++k)
-#pragma unroll
-        for (int i = 0; i < V; ++i) w[p][k][i] = w[p][k + 1][i];
-#pragma unroll
-      for (int i = 0; i < V; ++i) w[p][FL - 1][i] = d[p][i];
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {     // Y-sust, RG, YV, Y-trans (window of plane 0 again), cvvdp_metric.py:554-560
-      const int p = (c == 3) ? 0 : c;
-      float acc[V];
-#pragma unroll
-      for (int i = 0; i < V; ++i) acc[i] = 0.0f;
-#pragma unroll
-      for (int k = 0; k < FL; ++k)
-#pragma unroll
-        for (int i = 0; i < V; ++i) acc[i] += w[p][k][i] * a.taps[c * CVVDP_MAX_FILTER_LEN + k];
-      store_run<V>(out + (int64_t)(2 * c + side) * a.o_plane + (int64_t)fi * o_item, acc);
+          for (int i = 0; i < V; ++i) w[p][k][i] = w[p][k + U][i];
     }
   }
-  // ---- epilogue: the last FL-1 frames become the next block's history
+  // ---- epilogue: the last FL-1 frames become the next block's history.  The final chunk held r+1 frames
+  // (r = (n-1) % U), so they sit at window positions r+1 .. r+FL-1.
   if (a.write_hist) {
+    const int r = (a.n_frames - 1) % U;
 #pragma unroll
-    for (int k = 0; k < FL - 1; ++k)
+    for (int rr = 0; rr < U; ++rr) {
+      if (r == rr) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) store_run<V>(hist + p * a.h_plane + (int64_t)k * a.h_slot, w[p][k + 1]);
+        for (int k = 0; k < FL - 1; ++k)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) store_run<V>(hist + p * a.h_plane + (int64_t)k * a.h_slot, w[p][rr + 1 + k]);
+      }
+    }
   }
 }
 
@@ -190,7 +212,8 @@ template <int DT, int FL>
 static void launch_fused(const FirArgs& a, hipStream_t s) {
   constexpr int VMAX = FL <= 17 ? 2 : 1;
   const int eb = dtype_bytes(a.dtype);
-  if (VMAX == 2 && a.P % 2 == 0 && can_vectorise(2, a.W, a.sb, a.sc, a.sf, a.sh, a.sw, a.src, eb)) {
+  static const int vcap = getenv("CVVDP_FIR_V") ? atoi(getenv("CVVDP_FIR_V")) : 1;   // tuning hook; 1 = scalar pixels + chunked window (fastest)
+  if (VMAX == 2 && vcap >= 2 && a.P % 2 == 0 && can_vectorise(2, a.W, a.sb, a.sc, a.sf, a.sh, a.sw, a.src, eb)) {
     dim3 grid((a.P / 2 + 255) / 256, a.batch, 2);
     hipLaunchKernelGGL((k_fir_fused<DT, FL, 2>), grid, dim3(256), 0, s, a);
   } else {

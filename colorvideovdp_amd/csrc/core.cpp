@@ -228,8 +228,18 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     lv.vec4 = lv.blur && (W % 8 == 0) && c.heatmap == CVVDP_HEATMAP_NONE;
     const int sw = lv.vec4 ? kBand4StripWidth : (lv.blur ? 256 - 2 * pad : 256);
     lv.n_strip = (W + sw - 1) / sw;
-    lv.n_seg = (H + 255) / 256;
-    lv.seg_h = (H + lv.n_seg - 1) / lv.n_seg;
+    // Row segments: 256 rows amortise the 12 blur-halo rows of a segment to < 5 % on the big levels; small
+    // levels are latency-bound (one block marches ~2.5 us per row), so they are cut into shorter segments
+    // until ~1500 blocks exist for a nominal 16-frame block (down to 16 rows).
+    {
+      const int per_seg = lv.n_strip * 16 * c.batch;   // nominal 16 frames in flight: the split must not depend on the
+                                                        // block size, or per-frame sums would round differently per block size
+      const int want = (1536 + per_seg - 1) / per_seg;
+      const int lo = (H + 255) / 256, hi = std::max(lo, (H + 15) / 16);
+      lv.n_seg = std::min(std::max(want, lo), hi);
+      lv.seg_h = (H + lv.n_seg - 1) / lv.n_seg;
+      lv.n_seg = (H + lv.seg_h - 1) / lv.seg_h;
+    }
     if (l + 1 < h->L && (H < 2 || W < 2)) return fail(h, CVVDP_E_ARG, "pyramid too deep for %dx%d", c.width, c.height);
     H = (H + 1) / 2; W = (W + 1) / 2;
   }

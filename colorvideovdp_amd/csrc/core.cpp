@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -41,6 +42,14 @@ struct cvvdp_handle {
   bool prof = false;
   std::vector<ProfEvent> events;
   size_t events_used = 0;
+  // two-stage software pipeline over blocks (video, no heat map): FIR + reduce of block k+1 run on the
+  // caller's stream while the band kernels of block k run on an internal stream; two pyramid sets.
+  bool pipeline = false;
+  size_t pyr_set_floats = 0;
+  int cur_set = 0;
+  hipStream_t band_stream = nullptr;
+  hipEvent_t ev_reduce[2] = {nullptr, nullptr}, ev_band[2] = {nullptr, nullptr};
+  bool band_pending[2] = {false, false};
 };
 
 namespace {
@@ -61,6 +70,29 @@ int check_launch(cvvdp_handle* h, const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, CVVDP_E_HIP, "%s: %s", what, hipGetErrorString(e));
   return CVVDP_OK;
+}
+
+float* gbase(const cvvdp_handle* h, int level, int set) { return h->ws + h->lv[level].g_off + (size_t)set * h->pyr_set_floats; }
+
+int ensure_pipeline_objects(cvvdp_handle* h) {
+  if (!h->pipeline || h->band_stream) return CVVDP_OK;
+  if (hipStreamCreateWithFlags(&h->band_stream, hipStreamNonBlocking) != hipSuccess) return fail(h, CVVDP_E_HIP, "cannot create the band stream");
+  for (int i = 0; i < 2; ++i) {
+    if (hipEventCreateWithFlags(&h->ev_reduce[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_band[i], hipEventDisableTiming) != hipSuccess)
+      return fail(h, CVVDP_E_HIP, "cannot create pipeline events");
+  }
+  return CVVDP_OK;
+}
+
+// make the caller's stream wait for every band stage still in flight (no host synchronisation)
+void join_pipeline(cvvdp_handle* h, hipStream_t s) {
+  for (int i = 0; i < 2; ++i) {
+    if (h->band_pending[i]) {
+      (void)hipStreamWaitEvent(s, h->ev_band[i], 0);
+      h->band_pending[i] = false;
+    }
+  }
 }
 
 struct ProfScope {
@@ -92,27 +124,46 @@ void heat_weights(const cvvdp_handle* h, bool baseband, float* w) {
   }
 }
 
+int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStream_t s);
+
 int run_pyramid_and_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, hipStream_t s) {
   const int B = h->c.batch, items = n_frames * B, L = h->L, nch = h->nch;
   const float K[5] = {0.25f - 0.4f / 2.0f, 0.25f, 0.4f, 0.25f, 0.25f - 0.4f / 2.0f};  // lpyr_dec.py:179
-  const bool heat = h->c.heatmap != CVVDP_HEATMAP_NONE;
+  const int set = h->pipeline ? h->cur_set : 0;
   for (int l = 0; l + 1 < L; ++l) {
     ProfScope ps(h, CVVDP_PROF_REDUCE, s);
     ReduceArgs r{};
-    r.in = h->ws + h->lv[l].g_off;
-    r.out = h->ws + h->lv[l + 1].g_off;
+    r.in = gbase(h, l, set);
+    r.out = gbase(h, l + 1, set);
     r.H = h->lv[l].H; r.W = h->lv[l].W; r.Ho = h->lv[l + 1].H; r.Wo = h->lv[l + 1].W;
     r.n_img = items; r.img_cap = h->items_cap; r.n_planes = 2 * nch;
     for (int i = 0; i < 5; ++i) r.k[i] = K[i];
     launch_reduce(r, s);
   }
   if (int e = check_launch(h, "reduce")) return e;
+  if (!h->pipeline) return run_bands(h, n_frames, q_frame_offset, 0, s);
+  // hand the pyramid set to the band stage on the internal stream; the caller's stream is free to start
+  // the next block's FIR + reduce into the other set
+  if (int e = ensure_pipeline_objects(h)) return e;
+  (void)hipEventRecord(h->ev_reduce[set], s);
+  (void)hipStreamWaitEvent(h->band_stream, h->ev_reduce[set], 0);
+  if (int e = run_bands(h, n_frames, q_frame_offset, set, h->band_stream)) return e;
+  (void)hipEventRecord(h->ev_band[set], h->band_stream);
+  h->band_pending[set] = true;
+  h->cur_set ^= 1;
+  return CVVDP_OK;
+}
+
+int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStream_t s) {
+  const int B = h->c.batch, items = n_frames * B, L = h->L, nch = h->nch;
+  const float K[5] = {0.25f - 0.4f / 2.0f, 0.25f, 0.4f, 0.25f, 0.25f - 0.4f / 2.0f};  // lpyr_dec.py:179
+  const bool heat = h->c.heatmap != CVVDP_HEATMAP_NONE;
   for (int l = 0; l + 1 < L; ++l) {
     const Level& lv = h->lv[l];
     ProfScope ps(h, l == 0 ? CVVDP_PROF_BAND0 : CVVDP_PROF_BAND_REST, s);
     BandArgs a{};
-    a.g = h->ws + lv.g_off;
-    a.gc = h->ws + h->lv[l + 1].g_off;
+    a.g = gbase(h, l, set);
+    a.gc = gbase(h, l + 1, set);
     a.H = lv.H; a.W = lv.W; a.Hc = h->lv[l + 1].H; a.Wc = h->lv[l + 1].W;
     a.items = items; a.items_cap = h->items_cap; a.nch = nch;
     a.seg_h = lv.seg_h; a.n_seg = lv.n_seg; a.n_strip = lv.n_strip;
@@ -148,7 +199,7 @@ int run_pyramid_and_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, hip
     const Level& lv = h->lv[L - 1];
     ProfScope ps(h, CVVDP_PROF_BAND_REST, s);
     BaseArgs b{};
-    b.g = h->ws + lv.g_off; b.H = lv.H; b.W = lv.W; b.items = items; b.items_cap = h->items_cap; b.nch = nch;
+    b.g = gbase(h, L - 1, set); b.H = lv.H; b.W = lv.W; b.items = items; b.items_cap = h->items_cap; b.nch = nch;
     fill_csf(h, L - 1, b.lut);
     b.logL_first = h->p.csf_logL_first; b.logL_last = h->p.csf_logL_last; b.sens_mul = h->p.sens_mul;
     b.q_out = h->ws + h->q_off; b.q_frames = h->c.n_frames; b.q_levels = L; b.q_frame_offset = q_frame_offset;
@@ -197,6 +248,11 @@ int cvvdp_create(const cvvdp_params* params, cvvdp_handle** out) {
 
 void cvvdp_destroy(cvvdp_handle* h) {
   if (!h) return;
+  if (h->band_stream) {
+    (void)hipStreamSynchronize(h->band_stream);
+    (void)hipStreamDestroy(h->band_stream);
+    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(h->ev_reduce[i]); (void)hipEventDestroy(h->ev_band[i]); }
+  }
   for (auto& e : h->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   delete h;
 }
@@ -205,6 +261,10 @@ const char* cvvdp_last_error(const cvvdp_handle* h) { return h ? h->err.c_str() 
 
 int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
   if (!h || !clip) return CVVDP_E_ARG;
+  if (h->band_stream && (h->band_pending[0] || h->band_pending[1])) {   // re-configuring with band work in flight
+    (void)hipStreamSynchronize(h->band_stream);
+    h->band_pending[0] = h->band_pending[1] = false;
+  }
   const cvvdp_clip& c = *clip;
   if (c.batch < 1 || c.height < 2 || c.width < 2 || c.n_frames < 1) return fail(h, CVVDP_E_ARG, "bad clip geometry");
   if (c.channels != 1 && c.channels != 3) return fail(h, CVVDP_E_ARG, "channels must be 1 or 3");
@@ -253,7 +313,15 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     off += hist;
     if (!fir_has_register_window(c.filter_len)) { h->hist_shadow_off = off; off += hist; }  // generic-FL path double-buffers the tail
   }
-  for (auto& lv : h->lv) { lv.g_off = off; off += align_up((size_t)2 * h->nch * h->items_cap * lv.P); }
+  {
+    static const bool pipe_env = !(getenv("CVVDP_PIPELINE") && atoi(getenv("CVVDP_PIPELINE")) == 0);
+    h->pipeline = pipe_env && c.is_video && c.heatmap == CVVDP_HEATMAP_NONE && !c.debug_dump && c.n_frames > c.block_frames;
+    const size_t start = off;
+    for (auto& lv : h->lv) { lv.g_off = off; off += align_up((size_t)2 * h->nch * h->items_cap * lv.P); }
+    h->pyr_set_floats = off - start;
+    if (h->pipeline) off += h->pyr_set_floats;   // second pyramid set
+    h->cur_set = 0;
+  }
   size_t pmax = 0;
   for (auto& lv : h->lv) pmax = std::max(pmax, (size_t)h->items_cap * lv.n_strip * lv.n_seg * 4);
   h->partial_off = off; off += align_up(pmax);
@@ -338,7 +406,12 @@ int cvvdp_process_block(cvvdp_handle* h, const void* t, const void* r, int32_t d
   f.raw_first = raw_first; f.write_hist = 1;
   f.hist = h->ws + h->hist_off;
   f.h_b = P0; f.h_slot = (int64_t)c.batch * P0; f.h_plane = (int64_t)(fl - 1) * f.h_slot; f.h_side = 3 * f.h_plane;
-  f.out = h->ws + h->lv[0].g_off; f.o_plane = (int64_t)h->items_cap * P0;
+  const int set = h->pipeline ? h->cur_set : 0;
+  if (h->pipeline && h->band_pending[set]) {   // this pyramid set is still being read by the band stage of block k-2
+    (void)hipStreamWaitEvent(s, h->ev_band[set], 0);
+    h->band_pending[set] = false;
+  }
+  f.out = gbase(h, 0, set); f.o_plane = (int64_t)h->items_cap * P0;
   for (int ch = 0; ch < 4; ++ch)
     for (int k = 0; k < fl; ++k) f.taps[ch * CVVDP_MAX_FILTER_LEN + k] = c.taps[ch * CVVDP_MAX_FILTER_LEN + (fl - 1 - k)];  // F.flip(0), :556
   for (int k = 0; k < fl - 1; ++k) {
@@ -363,6 +436,7 @@ int cvvdp_process_image(cvvdp_handle* h, void* stream) {
 int cvvdp_get_q_per_ch(cvvdp_handle* h, float* dev_out, void* stream) {
   if (!h || !h->ws) return fail(h, CVVDP_E_STATE, "no workspace bound");
   if (!dev_out) return fail(h, CVVDP_E_ARG, "null output");
+  join_pipeline(h, static_cast<hipStream_t>(stream));
   const size_t n = (size_t)h->c.batch * h->nch * h->c.n_frames * h->L;
   hipError_t e = hipMemcpyAsync(dev_out, h->ws + h->q_off, n * sizeof(float), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(h, CVVDP_E_HIP, "copy Q_per_ch: %s", hipGetErrorString(e));

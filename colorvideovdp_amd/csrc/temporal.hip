@@ -79,13 +79,20 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
   for (int k = 0; k < FL - 1; ++k) {
     const int e = a.hist_src[k];
     if (e >= 0) {       // raw frame e of the block handed in by the host
-      float in[3][V], d[3][V];
-      load_pixels<DT, V>(a, side, off0 + e * sf, in);
-      convert_pixels<DT, V>(a, in, d);
+      if (k > 0 && e == a.hist_src[k - 1]) {   // replicate padding: the same frame again (uniform test)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int i = 0; i < V; ++i) w[p][k][i] = d[p][i];
+          for (int i = 0; i < V; ++i) w[p][k][i] = w[p][k - 1][i];
+      } else {
+        float in[3][V], d[3][V];
+        load_pixels<DT, V>(a, side, off0 + e * sf, in);
+        convert_pixels<DT, V>(a, in, d);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int i = 0; i < V; ++i) w[p][k][i] = d[p][i];
+      }
     } else {            // slot -1-e of the previous block's tail
 #pragma unroll
       for (int p = 0; p < 3; ++p) load_f32_run<V>(hist + p * a.h_plane + (int64_t)(-1 - e) * a.h_slot, w[p][k]);

@@ -14,6 +14,9 @@
 //     expressed by the host as "history entry k = raw frame index e" and converted in the prologue.
 // The next frame's samples are loaded before the current frame's FMAs (software prefetch).
 #include "photometry_dev.h"
+#ifndef CVVDP_FIR_PF
+#define CVVDP_FIR_PF 3
+#endif
 #include <cstdlib>
 
 namespace cvvdp {
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
   const int64_t o_item = (int64_t)a.batch * a.P;
   // software prefetch PF frames deep: with ~130 VGPRs only 3 waves/SIMD are resident, so the bytes in
   // flight per CU have to come from depth (3 waves x 4 SIMDs x PF frames x 3 loads x 512 B ~ 55 KB)
-  constexpr int PF = 3;
+  constexpr int PF = CVVDP_FIR_PF;
   float pf[PF][3][V];
 #pragma unroll
   for (int q = 0; q < PF; ++q)

@@ -295,13 +295,27 @@ class cvvdp(vq_metric):
         stream = torch.cuda.current_stream(self.device).cuda_stream
         heatmap = None
         hm_ch = 1 if self.heatmap == "raw" else 3
+        copy_stream = None
         if self.do_heatmap:
-            heatmap = torch.zeros([1, hm_ch, count, height, width], dtype=torch.float16, device="cpu")
+            # The reference keeps the whole fp16 heat map on the CPU (cvvdp_metric.py:344).  Page-locked memory
+            # + copies on a side stream keep the D2H traffic (6 B/pixel) off the compute stream.
+            shape = [1, hm_ch, count, height, width]
+            try:
+                heatmap = torch.zeros(shape, dtype=torch.float16, device="cpu", pin_memory=True)
+                copy_stream = torch.cuda.Stream(self.device)
+            except RuntimeError:
+                heatmap = torch.zeros(shape, dtype=torch.float16, device="cpu")
 
         def fetch_heatmap(ff, n):
             buf = torch.empty((hm_ch, n, height, width), dtype=torch.float16, device=self.device)
             _capi.check(self._handle, lib.cvvdp_get_heatmap(self._handle, n, buf.data_ptr(), stream), "cvvdp_get_heatmap")
-            heatmap[0, :, ff:ff + n] = buf.cpu()
+            if copy_stream is None:
+                heatmap[0, :, ff:ff + n] = buf.cpu()
+            else:
+                copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(copy_stream):
+                    heatmap[0, :, ff:ff + n].copy_(buf, non_blocking=True)
+                buf.record_stream(copy_stream)
 
         if is_image:
             st, sr = self._strides(probe_t, probe_r)
@@ -343,6 +357,8 @@ class cvvdp(vq_metric):
                 del t, r  # stream-ordered: safe to release to the caching allocator once the kernels are queued
         Q = torch.empty((B, nch, count, L), dtype=torch.float32, device=self.device)
         _capi.check(self._handle, lib.cvvdp_get_q_per_ch(self._handle, Q.data_ptr(), stream), "cvvdp_get_q_per_ch")
+        if copy_stream is not None:
+            copy_stream.synchronize()   # the heat map is host data: it must be complete when predict() returns
         return Q, heatmap, rho_band
 
     # ------------------------------------------------------------------ pooling, info, outputs

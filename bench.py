@@ -193,7 +193,7 @@ def main():
                 tj = json.load(f)
             if tj.get("workload") == args.workload and tj.get("dtype") == args.dtype:
                 traffic = tj.get("hbm_bytes_per_launch")
-        out["roofline"] = {"bound": "hbm", "kernel": "k_band<4,true> level 0 (fused expand/contrast/CSF/masking/pooling)",
+        out["roofline"] = {"bound": "hbm", "kernel": "k_band4<4> level 0 (fused expand/contrast/CSF/masking/blur/pooling)",
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": n,
                            "algorithmic_bytes_per_launch": BAND0_BYTES_PER_PIXEL * W * H * frames_per_launch}

@@ -145,11 +145,15 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     ex[3] = C * eo + D * eo;
   };
 
-  float win[B4_BW][4];
+  // Vertical-blur window: slot s of column i holds one horizontally blurred row.  The newest row is written
+  // into slot (row index mod 13) with an M0-relative register write (dynamic insertelement on a register
+  // vector); the 13 weights -- wave-uniform scalars -- are rotated instead of the data, so the FMAs use
+  // static register indices and no 13-way switch / PHI copies are needed.
+  typedef float v16f __attribute__((ext_vector_type(16)));
+  v16f win0 = 0.0f, win1 = 0.0f, win2 = 0.0f, win3 = 0.0f;
+  float wr[B4_BW];     // wr[s] = weight of slot s for the NEXT row to be written into slot 0
 #pragma unroll
-  for (int k = 0; k < B4_BW; ++k)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) win[k][i] = 0.0f;
+  for (int k = 0; k < B4_BW; ++k) wr[k] = a.blur[(k + B4_BW - 1) % B4_BW];
   float acc = 0.0f;
 
   // pooling stage of centre row y (cvvdp_metric.py:849-856, 722): needs s_q of all channels and s_d
@@ -268,21 +272,17 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
         h[i] = s;
       }
       float v[4];
-      const int slot = (r - (ys - B4_R)) % B4_BW;
-      switch (slot) {
-        case 0: win4_step<0>(win, h, a.blur, v); break;
-        case 1: win4_step<1>(win, h, a.blur, v); break;
-        case 2: win4_step<2>(win, h, a.blur, v); break;
-        case 3: win4_step<3>(win, h, a.blur, v); break;
-        case 4: win4_step<4>(win, h, a.blur, v); break;
-        case 5: win4_step<5>(win, h, a.blur, v); break;
-        case 6: win4_step<6>(win, h, a.blur, v); break;
-        case 7: win4_step<7>(win, h, a.blur, v); break;
-        case 8: win4_step<8>(win, h, a.blur, v); break;
-        case 9: win4_step<9>(win, h, a.blur, v); break;
-        case 10: win4_step<10>(win, h, a.blur, v); break;
-        case 11: win4_step<11>(win, h, a.blur, v); break;
-        default: win4_step<12>(win, h, a.blur, v); break;
+      const int slot = (r - (ys - B4_R)) % B4_BW;          // wave-uniform
+      win0[slot] = h[0]; win1[slot] = h[1]; win2[slot] = h[2]; win3[slot] = h[3];
+      // weight of slot s when the newest row sits in `slot`: window position j = (s - slot - 1) mod 13 -> wr[]
+      // is kept rotated so that wr[s] is exactly that weight
+      {
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+        for (int sdx = 0; sdx < B4_BW; ++sdx) {
+          a0 += wr[sdx] * win0[sdx]; a1 += wr[sdx] * win1[sdx]; a2 += wr[sdx] * win2[sdx]; a3 += wr[sdx] * win3[sdx];
+        }
+        v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
       }
       if (yc >= ys) {
         float Mq[4];
@@ -290,6 +290,12 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
         for (int i = 0; i < 4; ++i) Mq[i] = fast_pow(fabsf(v[i] * a.mask_c10) + kEps, qc) - eps_qc;   // cvvdp_metric.py:849
         lds_write4(&s_q[c][4 * j], Mq);
       }
+    }
+    {   // rotate the blur weights for the next row (scalar ALU)
+      const float last = wr[B4_BW - 1];
+#pragma unroll
+      for (int k = B4_BW - 1; k > 0; --k) wr[k] = wr[k - 1];
+      wr[0] = last;
     }
     if (more) {
       stage1_finish(rn);

@@ -33,20 +33,6 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 
 __device__ __forceinline__ float safe_powf(float x, float p, float eps_p) { return powf(x + kEps, p) - eps_p; }
 
-// One step of the rotating 13-row window: store the new row in slot S, blur the 13 rows vertically.
-template <int S, int NCH>
-__device__ __forceinline__ void window_step(float (&win)[BW][NCH], const float (&h)[4], const float* bw, float (&v)[4]) {
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) win[S][c] = h[c];
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    float acc = 0.0f;
-#pragma unroll
-    for (int j = 0; j < BW; ++j) acc += bw[j] * win[(S + 1 + j) % BW][c];  // oldest row first
-    v[c] = acc;
-  }
-}
-
 template <int NCH, bool BLUR>
 __global__ __launch_bounds__(BT) void k_band(BandArgs a) {
   constexpr int R = BLUR ? BR : 0;
@@ -84,11 +70,13 @@ __global__ __launch_bounds__(BT) void k_band(BandArgs a) {
   const float ind_scale = (float)(CVVDP_CSF_NODES - 1) / (a.logL_last - a.logL_first);
   if (t < 4 * CVVDP_CSF_NODES) s_lut[t] = a.lut[t] * kLog2_10 + fast_log2(a.sens_mul);
 
-  float win[BW][NCH];
+  // 13-row vertical-blur window per channel as a register vector: the newest row goes to slot (row mod 13)
+  // through an M0-relative register write; the scalar weights are rotated instead of the data (cf. band4.hip)
+  typedef float v16f __attribute__((ext_vector_type(16)));
+  v16f win[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float wr[BW];
 #pragma unroll
-  for (int j = 0; j < BW; ++j)
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) win[j][c] = 0.0f;
+  for (int k = 0; k < BW; ++k) wr[k] = a.blur[(k + BW - 1) % BW];
   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
   for (int r = ys - R; r < ye + R; ++r) {
@@ -164,27 +152,27 @@ __global__ __launch_bounds__(BT) void k_band(BandArgs a) {
           for (int k = 0; k < BW; ++k) s += a.blur[k] * s_m[c][t - R + k];
           h[c] = s;
         }
-        const int slot = (r - (ys - R)) % BW;
-        switch (slot) {
-          case 0: window_step<0, NCH>(win, h, a.blur, v); break;
-          case 1: window_step<1, NCH>(win, h, a.blur, v); break;
-          case 2: window_step<2, NCH>(win, h, a.blur, v); break;
-          case 3: window_step<3, NCH>(win, h, a.blur, v); break;
-          case 4: window_step<4, NCH>(win, h, a.blur, v); break;
-          case 5: window_step<5, NCH>(win, h, a.blur, v); break;
-          case 6: window_step<6, NCH>(win, h, a.blur, v); break;
-          case 7: window_step<7, NCH>(win, h, a.blur, v); break;
-          case 8: window_step<8, NCH>(win, h, a.blur, v); break;
-          case 9: window_step<9, NCH>(win, h, a.blur, v); break;
-          case 10: window_step<10, NCH>(win, h, a.blur, v); break;
-          case 11: window_step<11, NCH>(win, h, a.blur, v); break;
-          default: window_step<12, NCH>(win, h, a.blur, v); break;
+        const int slot = (r - (ys - R)) % BW;     // block-uniform
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) win[c][slot] = h[c];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          float acc = 0.0f;
+#pragma unroll
+          for (int sdx = 0; sdx < BW; ++sdx) acc += wr[sdx] * win[c][sdx];
+          v[c] = acc;
         }
         if (have) {
           const int cslot = ((yc % (R + 1)) + (R + 1)) % (R + 1);
 #pragma unroll
           for (int c = 0; c < NCH; ++c) d[c] = s_d[cslot][c][t];
         }
+      }
+      {   // rotate the blur weights for the next row (scalar ALU)
+        const float last = wr[BW - 1];
+#pragma unroll
+        for (int k = BW - 1; k > 0; --k) wr[k] = wr[k - 1];
+        wr[0] = last;
       }
     } else {
 #pragma unroll

@@ -40,19 +40,6 @@ __device__ __forceinline__ void lds_write4(float* p, const float (&v)[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-template <int S>
-__device__ __forceinline__ void win4_step(float (&win)[B4_BW][4], const float (&h)[4], const float* bw, float (&v)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) win[S][i] = h[i];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float acc = 0.0f;
-#pragma unroll
-    for (int j = 0; j < B4_BW; ++j) acc += bw[j] * win[(S + 1 + j) % B4_BW][i];
-    v[i] = acc;
-  }
-}
-
 __device__ __forceinline__ int refl(int i, int n) {
   if (i < 0) i = -i;
   if (i >= n) i = 2 * (n - 1) - i;

@@ -12,7 +12,7 @@ MAX_WINDOW = 256
 CSF_NODES = 32
 PROF_N = 6
 PROF_NAMES = ("photometry", "temporal_fir", "pyr_reduce", "band_level0", "band_rest", "heatmap")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 U8, U16, F16, F32, F32_DKL = range(5)
 HEATMAP = {None: 0, "none": 0, "raw": 1, "threshold": 2, "supra-threshold": 3}
@@ -48,6 +48,7 @@ class Clip(C.Structure):
         ("height", C.c_int32), ("width", C.c_int32),
         ("is_video", C.c_int32),
         ("n_frames", C.c_int32),
+        ("first_frame", C.c_int32),
         ("n_levels", C.c_int32),
         ("filter_len", C.c_int32),
         ("block_frames", C.c_int32),

@@ -404,6 +404,7 @@ int cvvdp_process_block(cvvdp_handle* h, const void* t, const void* r, int32_t d
   fill_display(h, f.dm);
   f.W = c.width; f.P = (int)P0; f.batch = c.batch; f.n_frames = n_frames; f.fl = fl;
   f.raw_first = raw_first; f.write_hist = 1;
+  f.abs_first = c.first_frame + q_frame_offset;
   f.hist = h->ws + h->hist_off;
   f.h_b = P0; f.h_slot = (int64_t)c.batch * P0; f.h_plane = (int64_t)(fl - 1) * f.h_slot; f.h_side = 3 * f.h_plane;
   const int set = h->pipeline ? h->cur_set : 0;
@@ -413,7 +414,8 @@ int cvvdp_process_block(cvvdp_handle* h, const void* t, const void* r, int32_t d
   }
   f.out = gbase(h, 0, set); f.o_plane = (int64_t)h->items_cap * P0;
   for (int ch = 0; ch < 4; ++ch)
-    for (int k = 0; k < fl; ++k) f.taps[ch * CVVDP_MAX_FILTER_LEN + k] = c.taps[ch * CVVDP_MAX_FILTER_LEN + (fl - 1 - k)];  // F.flip(0), :556
+    for (int k = 0; k < std::min(2 * fl, CVVDP_MAX_FILTER_LEN); ++k)   // F.flip(0) (:556), written twice back to back so
+      f.taps[ch * CVVDP_MAX_FILTER_LEN + k] = c.taps[ch * CVVDP_MAX_FILTER_LEN + (fl - 1 - (k % fl))];   // that a rotated view is contiguous
   for (int k = 0; k < fl - 1; ++k) {
     const int e = hist_src[k];
     if (e >= 32767 || e < -(fl - 1)) return fail(h, CVVDP_E_ARG, "hist_src[%d] = %d out of range", k, e);

@@ -51,6 +51,7 @@ struct FirArgs {
   DisplayArgs dm;
   int32_t W, P, batch, n_frames, fl;
   int32_t raw_first;       // raw frame index of the block's first scored frame
+  int32_t abs_first;       // clip index of that frame (window rotation phase)
   int32_t write_hist;      // store the last fl-1 DKL frames for the next block
   float* hist;             // [side][plane][slot][b][P]: DKL tail of the previous block
   int64_t h_side, h_plane, h_slot, h_b;

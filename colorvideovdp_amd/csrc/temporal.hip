@@ -167,6 +167,94 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// 60 fps fast path (FL = 17, one pixel per thread): the FL-deep window of each DKL plane is a register
+// vector; the newest frame is written to slot (frame index mod 17) with an M0-relative register write and
+// the taps are read rotated instead (scalar loads from a doubled tap table), so nothing is shifted and
+// the window costs 51 VGPRs: 5-6 waves per SIMD hide the HBM latency this kernel is bound by.
+template <int DT>
+__global__ __launch_bounds__(256) void k_fir_rot17(FirArgs a) {
+  constexpr int FL = 17;
+  typedef float v16f __attribute__((ext_vector_type(16)));
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= a.P) return;
+  const int b = blockIdx.y, side = blockIdx.z;
+  const int y = pix / a.W, x = pix - y * a.W;
+  const int64_t off0 = b * a.sb[side] + (int64_t)y * a.sh[side] + (int64_t)x * a.sw[side];
+  const int64_t sf = a.sf[side];
+  float* hist = a.hist + side * a.h_side + b * a.h_b + pix;
+
+  v16f wlo[3];          // slots 0..15
+  float whi[3];         // slot 16
+  auto put = [&](int slot, const float (&d)[3][1]) {   // slot is wave-uniform
+    if (slot < 16) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wlo[p][slot] = d[p][0];
+    } else {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) whi[p] = d[p][0];
+    }
+  };
+  // Slot of a frame = its clip index mod FL, so the order in which a frame's 17 products are summed does not
+  // depend on how the clip is cut into blocks or shards (bit-identical results for any blocking).
+  int slot = ((a.abs_first - (FL - 1)) % FL + FL) % FL;     // slot of window position 0 of the first scored frame
+  // ---- prologue: window positions 0..FL-2
+  for (int k = 0; k < FL - 1; ++k) {
+    const int e = a.hist_src[k];
+    float d[3][1];
+    if (e >= 0) {
+      float in[3][1];
+      load_pixels<DT, 1>(a, side, off0 + e * sf, in);
+      convert_pixels<DT, 1>(a, in, d);
+    } else {
+      for (int p = 0; p < 3; ++p) d[p][0] = hist[p * a.h_plane + (int64_t)(-1 - e) * a.h_slot];
+    }
+    put(slot, d);
+    slot = (slot + 1 == FL) ? 0 : slot + 1;
+  }
+  float* out = a.out + (int64_t)b * a.P + pix;
+  const int64_t o_item = (int64_t)a.batch * a.P;
+  constexpr int PF = CVVDP_FIR_PF;
+  float pf[PF][3][1];
+#pragma unroll
+  for (int q = 0; q < PF; ++q)
+    if (q < a.n_frames) load_pixels<DT, 1>(a, side, off0 + (int64_t)(a.raw_first + q) * sf, pf[q]);
+  // `slot` is now where the next frame is written; window position k then sits in slot (slot+1+k) % FL
+  for (int fi = 0; fi < a.n_frames; ++fi) {
+    float d[3][1];
+    convert_pixels<DT, 1>(a, pf[0], d);
+#pragma unroll
+    for (int q = 0; q + 1 < PF; ++q)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) pf[q][p][0] = pf[q + 1][p][0];
+    if (fi + PF < a.n_frames) load_pixels<DT, 1>(a, side, off0 + (int64_t)(a.raw_first + fi + PF) * sf, pf[PF - 1]);
+    put(slot, d);
+    // slot s holds window position (s - slot - 1) mod FL: its weight is taps2[c][FL - 1 - slot + s], taps2 = taps ++ taps
+    const float* tb = a.taps + (FL - 1 - slot);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {     // Y-sust, RG, YV, Y-trans (window of plane 0 again), cvvdp_metric.py:554-560
+      const int p = (c == 3) ? 0 : c;
+      const float* t = tb + c * CVVDP_MAX_FILTER_LEN;
+      float acc = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc += wlo[p][s] * t[s];
+      acc += whi[p] * t[16];
+      out[(int64_t)(2 * c + side) * a.o_plane + (int64_t)fi * o_item] = acc;
+    }
+    slot = (slot + 1 == FL) ? 0 : slot + 1;
+  }
+  // ---- epilogue: the last FL-1 frames in time order: window positions 1..FL-1 of the last frame's window;
+  // after the loop `slot` is the slot of the OLDEST entry, so position k (k >= 1) sits in slot (slot + k) % FL
+  if (a.write_hist) {
+    for (int k = 0; k < FL - 1; ++k) {
+      const int s = (slot + 1 + k) % FL;     // uniform
+#pragma unroll
+      for (int p = 0; p < 3; ++p) hist[p * a.h_plane + (int64_t)k * a.h_slot] = (s < 16) ? wlo[p][s] : whi[p];
+    }
+  }
+}
+
 // Any filter length (odd frame rates): no register window; every tap re-reads and re-converts its frame.
 template <int DT>
 __global__ __launch_bounds__(256) void k_fir_generic(FirArgs a) {
@@ -228,7 +316,9 @@ static void launch_fused(const FirArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((k_fir_fused<DT, FL, 2>), grid, dim3(256), 0, s, a);
   } else {
     dim3 grid((a.P + 255) / 256, a.batch, 2);
-    hipLaunchKernelGGL((k_fir_fused<DT, FL, 1>), grid, dim3(256), 0, s, a);
+    static const bool rot = !(getenv("CVVDP_FIR_ROT") && atoi(getenv("CVVDP_FIR_ROT")) == 0);
+    if (FL == 17 && rot) hipLaunchKernelGGL((k_fir_rot17<DT>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_fir_fused<DT, FL, 1>), grid, dim3(256), 0, s, a);
   }
 }
 

@@ -266,6 +266,7 @@ class cvvdp(vq_metric):
         clip = _capi.Clip()
         clip.batch, clip.channels, clip.height, clip.width = B, C, height, width
         clip.is_video, clip.n_frames, clip.n_levels = int(not is_image), count, L
+        clip.first_frame = first
         clip.heatmap = _capi.HEATMAP[self.heatmap]
         clip.debug_dump = int(self.debug_dump)
         fl = 1

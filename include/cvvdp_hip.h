@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CVVDP_ABI_VERSION 2
+#define CVVDP_ABI_VERSION 3
 #define CVVDP_MAX_FILTER_LEN 65 /* 0.25 s at up to 256 fps, cvvdp_metric.py:1059 */
 #define CVVDP_MAX_LEVELS 16
 #define CVVDP_MAX_WINDOW 256    /* filter_len - 1 + frames per block */
@@ -89,6 +89,8 @@ typedef struct cvvdp_clip {
   int32_t height, width;
   int32_t is_video;             /* 0: image (3 channels, no temporal filter), 1: video (4 channels) */
   int32_t n_frames;             /* frames this handle scores (capacity of Q_per_ch along F) */
+  int32_t first_frame;          /* clip index of the first scored frame (0, or the start of a frame-range shard): keys the
+                                   temporal-window rotation so that per-frame sums round identically for any blocking */
   int32_t n_levels;             /* pyramid band count (lpyr.get_band_count()) */
   int32_t filter_len;           /* temporal filter length (video) */
   int32_t block_frames;         /* max frames per process_block call */

@@ -101,11 +101,12 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   };
   auto stage1_finish = [&](int rr) {
     auto fix = [&](const float4& q) -> f4 {
-      if (edge_block) {
-        if (clampL) return f4{{q.x, q.x, q.x, q.x}};
-        if (clampR) return f4{{q.w, q.w, q.w, q.w}};
+      f4 o = f4{{q.x, q.y, q.z, q.w}};
+      if (edge_block) {                          // block-uniform; lanes differ only in the select below
+        const float rep = clampL ? q.x : q.w;    // replicate column 0 / Wc-1 for chunks left / right of the image
+        if (clampL || clampR) { o.v[0] = rep; o.v[1] = rep; o.v[2] = rep; o.v[3] = rep; }
       }
-      return f4{{q.x, q.y, q.z, q.w}};
+      return o;
     };
     const f4 m0 = fix(cA), m1 = fix(cB), m2 = fix(cC);
     float o[4];
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     // ================= phase 1
     const int yprev = r - 1 - B4_R;                  // row whose Mq was published last iteration
     if (interior && yprev >= ys) stage3c(yprev);
-    float m[4] = {0.0f, 0.0f, 0.0f, 0.0f}, d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float m[4], d[4];
     if (in_img) {
       float exT[4], exR[4], eyT[4], eyR[4];
       expand4(s_ve[2 * c], exT);
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     // (coarse rows -> s_ve) and in the next phase 1 (g), i.e. behind the ~120 FMAs of the blur
     const bool more = r + 1 < ye + B4_R;
     const int rn = refl(r + 1, H);
-    float4 nT = make_float4(0, 0, 0, 0), nR = make_float4(0, 0, 0, 0);
+    float4 nT, nR;   // only read when this lane's columns are inside the image (no zero fill: saves 8 v_mov per row)
     if (more) {
       stage1_load(rn);
       if (in_img) {

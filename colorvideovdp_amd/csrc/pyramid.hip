@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void k_reduce_vec(ReduceArgs a) {
   };
 #pragma unroll
   for (int k = 0; k < 3; ++k) hrow(2 * oy0 - 2 + k, w[k]);         // rows 2oy-2, 2oy-1, 2oy of the first output
+#pragma unroll 4
   for (int oy = oy0; oy < oy1; ++oy) {
     if (oy > oy0) {
 #pragma unroll

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_fir_rot17(FirArgs a) {
 #pragma unroll
       for (int s = 0; s < 16; ++s) acc += wlo[p][s] * t[s];
       acc += whi[p] * t[16];
-      out[(int64_t)(2 * c + side) * a.o_plane + (int64_t)fi * o_item] = acc;
+      __builtin_nontemporal_store(acc, &out[(int64_t)(2 * c + side) * a.o_plane + (int64_t)fi * o_item]);   // streamed once, read by later kernels
     }
     slot = (slot + 1 == FL) ? 0 : slot + 1;
   }

@@ -31,6 +31,11 @@ constexpr int B4_SW = 256 - 2 * B4_HALO;  // 240 interior columns per strip
 constexpr int B4_VE = 136;         // s_ve row: element 4+i = coarse column cb+i (i = 0..127), 16-byte aligned chunks
 
 struct f4 { float v[4]; };
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream4(const float* p) {   // read-once data: nontemporal, stays out of L2
+  const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+  return make_float4(q.x, q.y, q.z, q.w);
+}
 
 __device__ __forceinline__ f4 lds_read4(const float* p) {
   const float4 q = *reinterpret_cast<const float4*>(p);
@@ -171,8 +176,8 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   stage1_load(rr);
   float4 pT = make_float4(0, 0, 0, 0), pR = make_float4(0, 0, 0, 0);
   if (in_img) {
-    pT = *reinterpret_cast<const float4*>(gT + (int64_t)rr * W + fc0);
-    pR = *reinterpret_cast<const float4*>(gR + (int64_t)rr * W + fc0);
+    pT = ld_stream4(gT + (int64_t)rr * W + fc0);
+    pR = ld_stream4(gR + (int64_t)rr * W + fc0);
   }
   stage1_finish(rr);
   __syncthreads();
@@ -241,8 +246,8 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     if (more) {
       stage1_load(rn);
       if (in_img) {
-        nT = *reinterpret_cast<const float4*>(gT + (int64_t)rn * W + fc0);
-        nR = *reinterpret_cast<const float4*>(gR + (int64_t)rn * W + fc0);
+        nT = ld_stream4(gT + (int64_t)rn * W + fc0);
+        nR = ld_stream4(gR + (int64_t)rn * W + fc0);
       }
     }
     const int yc = r - B4_R;

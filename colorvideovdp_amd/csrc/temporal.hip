@@ -169,13 +169,13 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------
-// 60 fps fast path (FL = 17, one pixel per thread): the FL-deep window of each DKL plane is a register
+// Fast path for FL <= 17 (24 .. 60 fps), one pixel per thread: the FL-deep window of each DKL plane is a register
 // vector; the newest frame is written to slot (frame index mod 17) with an M0-relative register write and
 // the taps are read rotated instead (scalar loads from a doubled tap table), so nothing is shifted and
 // the window costs 51 VGPRs: 5-6 waves per SIMD hide the HBM latency this kernel is bound by.
-template <int DT>
-__global__ __launch_bounds__(256) void k_fir_rot17(FirArgs a) {
-  constexpr int FL = 17;
+template <int DT, int FL>
+__global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
+  static_assert(FL <= 17, "window = one 16-wide register vector (+1 scalar slot)");
   typedef float v16f __attribute__((ext_vector_type(16)));
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= a.P) return;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_fir_rot17(FirArgs a) {
   v16f wlo[3];          // slots 0..15
   float whi[3];         // slot 16
   auto put = [&](int slot, const float (&d)[3][1]) {   // slot is wave-uniform
-    if (slot < 16) {
+    if (FL <= 16 || slot < 16) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) wlo[p][slot] = d[p][0];
     } else {
@@ -238,8 +238,8 @@ __global__ __launch_bounds__(256) void k_fir_rot17(FirArgs a) {
       const float* t = tb + c * CVVDP_MAX_FILTER_LEN;
       float acc = 0.0f;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) acc += wlo[p][s] * t[s];
-      acc += whi[p] * t[16];
+      for (int s = 0; s < (FL < 16 ? FL : 16); ++s) acc += wlo[p][s] * t[s];
+      if constexpr (FL == 17) acc += whi[p] * t[16];
       __builtin_nontemporal_store(acc, &out[(int64_t)(2 * c + side) * a.o_plane + (int64_t)fi * o_item]);   // streamed once, read by later kernels
     }
     slot = (slot + 1 == FL) ? 0 : slot + 1;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_fir_rot17(FirArgs a) {
     for (int k = 0; k < FL - 1; ++k) {
       const int s = (slot + 1 + k) % FL;     // uniform
 #pragma unroll
-      for (int p = 0; p < 3; ++p) hist[p * a.h_plane + (int64_t)k * a.h_slot] = (s < 16) ? wlo[p][s] : whi[p];
+      for (int p = 0; p < 3; ++p) hist[p * a.h_plane + (int64_t)k * a.h_slot] = (FL <= 16 || s < 16) ? wlo[p][s] : whi[p];
     }
   }
 }
@@ -317,8 +317,10 @@ static void launch_fused(const FirArgs& a, hipStream_t s) {
   } else {
     dim3 grid((a.P + 255) / 256, a.batch, 2);
     static const bool rot = !(getenv("CVVDP_FIR_ROT") && atoi(getenv("CVVDP_FIR_ROT")) == 0);
-    if (FL == 17 && rot) hipLaunchKernelGGL((k_fir_rot17<DT>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_fir_fused<DT, FL, 1>), grid, dim3(256), 0, s, a);
+    if constexpr (FL <= 17) {
+      if (rot) { hipLaunchKernelGGL((k_fir_rot<DT, FL>), grid, dim3(256), 0, s, a); return; }
+    }
+    hipLaunchKernelGGL((k_fir_fused<DT, FL, 1>), grid, dim3(256), 0, s, a);
   }
 }
 

@@ -32,6 +32,7 @@ constexpr int B4_VE = 136;         // s_ve row: element 4+i = coarse column cb+i
 
 struct f4 { float v[4]; };
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 ld_stream4(const float* p) {   // read-once data: nontemporal, stays out of L2
   const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
   return make_float4(q.x, q.y, q.z, q.w);
@@ -105,22 +106,18 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     cC = *reinterpret_cast<const float4*>(gcp + (int64_t)yb * Wc + cx);
   };
   auto stage1_finish = [&](int rr) {
-    auto fix = [&](const float4& q) -> f4 {
-      f4 o = f4{{q.x, q.y, q.z, q.w}};
-      if (edge_block) {                          // block-uniform; lanes differ only in the select below
-        const float rep = clampL ? q.x : q.w;    // replicate column 0 / Wc-1 for chunks left / right of the image
-        if (clampL || clampR) { o.v[0] = rep; o.v[1] = rep; o.v[2] = rep; o.v[3] = rep; }
-      }
-      return o;
-    };
-    const f4 m0 = fix(cA), m1 = fix(cB), m2 = fix(cC);
+    if (edge_block && (clampL || clampR)) {      // replicate column 0 / Wc-1 for chunks left / right of the image
+      const float ra = clampL ? cA.x : cA.w, rb = clampL ? cB.x : cB.w, rc = clampL ? cC.x : cC.w;
+      cA = make_float4(ra, ra, ra, ra); cB = make_float4(rb, rb, rb, rb); cC = make_float4(rc, rc, rc, rc);
+    }
+    const float m0[4] = {cA.x, cA.y, cA.z, cA.w}, m1[4] = {cB.x, cB.y, cB.z, cB.w}, m2[4] = {cC.x, cC.y, cC.z, cC.w};
     float o[4];
     if (rr & 1) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = m1.v[i] * eo + m2.v[i] * eo;
+      for (int i = 0; i < 4; ++i) o[i] = m1[i] * eo + m2[i] * eo;
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = m0.v[i] * e0 + m1.v[i] * e1 + m2.v[i] * e0;
+      for (int i = 0; i < 4; ++i) o[i] = m0[i] * e0 + m1[i] * e1 + m2[i] * e0;
     }
     lds_write4(reinterpret_cast<float*>(&s_ve[vp][2 + 2 * vch]), o);
   };
@@ -142,8 +139,12 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   // into slot (row index mod 13) with an M0-relative register write (dynamic insertelement on a register
   // vector); the 13 weights -- wave-uniform scalars -- are rotated instead of the data, so the FMAs use
   // static register indices and no 13-way switch / PHI copies are needed.
-  typedef float v16f __attribute__((ext_vector_type(16)));
-  v16f win0 = 0.0f, win1 = 0.0f, win2 = 0.0f, win3 = 0.0f;
+  typedef float v32f __attribute__((ext_vector_type(32)));
+  v32f winA = 0.0f, winB = 0.0f;   // columns (0,1) and (2,3) interleaved: element 2s+i = slot s of column i
+  v2f be[6], bo[6];
+#pragma unroll
+  for (int m = 0; m < 6; ++m) { be[m] = v2f{a.blur[2 * m], a.blur[2 * m + 1]}; bo[m] = v2f{a.blur[2 * m + 1], a.blur[2 * m + 2]}; }
+  const float b0 = a.blur[0], b12 = a.blur[12];
   float wr[B4_BW];     // wr[s] = weight of slot s for the NEXT row to be written into slot 0
 #pragma unroll
   for (int k = 0; k < B4_BW; ++k) wr[k] = a.blur[(k + B4_BW - 1) % B4_BW];
@@ -188,33 +189,36 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     if (interior && yprev >= ys) stage3c(yprev);
     float m[4], d[4];
     if (in_img) {
-      float exT[4], exR[4], eyT[4], eyR[4];
+      float exT[4], exR[4];
       expand4(s_ve[2 * c], exT);
       expand4(s_ve[2 * c + 1], exR);
-      if (c == 0) {
+      const float gt[4] = {pT.x, pT.y, pT.z, pT.w}, gr[4] = {pR.x, pR.y, pR.z, pR.w};
+      auto contrast = [&](const float (&eyT)[4], const float (&eyR)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { eyT[i] = exT[i]; eyR[i] = exR[i]; }
+        for (int i = 0; i < 4; ++i) {
+          const float Lt = fmaxf(eyT[i], 0.01f), Lr = fmaxf(eyR[i], 0.01f);      // lpyr_dec.py:394
+          const float rLt = fast_rcp(Lt), rLr = fast_rcp(Lr);
+          float ind = (fast_log2(Lr) * kLog10_2 - a.logL_first) * ind_scale;     // lpyr_dec.py:408, interp.py:93
+          ind = fminf(fmaxf(ind, 0.0f), (float)(CVVDP_CSF_NODES - 1));
+          const int i0 = (int)ind;
+          const float fr = ind - (float)i0;
+          const int i1 = min(i0 + 1, CVVDP_CSF_NODES - 1);
+          const float l0 = s_lut[c][i0], l1 = s_lut[c][i1];
+          const float S = fast_exp2(l0 + (l1 - l0) * fr);                        // csf.py:49, cvvdp_metric.py:709,:836
+          const float ct = fminf((gt[i] - exT[i]) * rLt, 1000.0f);               // lpyr_dec.py:402 (band gain :66 is in S)
+          const float cr = fminf((gr[i] - exR[i]) * rLr, 1000.0f);
+          const float Tp = ct * S, Rp = cr * S;
+          m[i] = fminf(fabsf(Tp), fabsf(Rp));                                    // cvvdp_metric.py:845
+          d[i] = fabsf(Tp - Rp);
+        }
+      };
+      if (c == 0) {                                   // wave-uniform: the luminance planes are this wave's own
+        contrast(exT, exR);
       } else {
+        float eyT[4], eyR[4];
         expand4(s_ve[0], eyT);
         expand4(s_ve[1], eyR);
-      }
-      const float gt[4] = {pT.x, pT.y, pT.z, pT.w}, gr[4] = {pR.x, pR.y, pR.z, pR.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float Lt = fmaxf(eyT[i], 0.01f), Lr = fmaxf(eyR[i], 0.01f);      // lpyr_dec.py:394
-        const float rLt = fast_rcp(Lt), rLr = fast_rcp(Lr);
-        float ind = (fast_log2(Lr) * kLog10_2 - a.logL_first) * ind_scale;     // lpyr_dec.py:408, interp.py:93
-        ind = fminf(fmaxf(ind, 0.0f), (float)(CVVDP_CSF_NODES - 1));
-        const int i0 = (int)ind;
-        const float fr = ind - (float)i0;
-        const int i1 = min(i0 + 1, CVVDP_CSF_NODES - 1);
-        const float l0 = s_lut[c][i0], l1 = s_lut[c][i1];
-        const float S = fast_exp2(l0 + (l1 - l0) * fr);                        // csf.py:49, cvvdp_metric.py:709,:836
-        const float ct = fminf((gt[i] - exT[i]) * rLt, 1000.0f);               // lpyr_dec.py:402 (band gain :66 is in S)
-        const float cr = fminf((gr[i] - exR[i]) * rLr, 1000.0f);
-        const float Tp = ct * S, Rp = cr * S;
-        m[i] = fminf(fabsf(Tp), fabsf(Rp));                                    // cvvdp_metric.py:845
-        d[i] = fabsf(Tp - Rp);
+        contrast(eyT, eyR);
       }
       lds_write4(&s_m[c][4 * j], m);
       const int ds = ((r % (B4_R + 1)) + (B4_R + 1)) % (B4_R + 1);
@@ -242,40 +246,47 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     // (coarse rows -> s_ve) and in the next phase 1 (g), i.e. behind the ~120 FMAs of the blur
     const bool more = r + 1 < ye + B4_R;
     const int rn = refl(r + 1, H);
-    float4 nT, nR;   // only read when this lane's columns are inside the image (no zero fill: saves 8 v_mov per row)
     if (more) {
       stage1_load(rn);
-      if (in_img) {
-        nT = ld_stream4(gT + (int64_t)rn * W + fc0);
-        nR = ld_stream4(gR + (int64_t)rn * W + fc0);
+      if (in_img) {                                   // pT / pR were consumed in phase 1: reload in place
+        pT = ld_stream4(gT + (int64_t)rn * W + fc0);
+        pR = ld_stream4(gR + (int64_t)rn * W + fc0);
       }
     }
     const int yc = r - B4_R;
     if (interior) {
-      const float* row = &s_m[c][4 * j - 8];
-      const f4 a0 = lds_read4(row), a1 = lds_read4(row + 4), a2 = lds_read4(row + 8), a3 = lds_read4(row + 12), a4 = lds_read4(row + 16);
-      const float x[20] = {a0.v[0], a0.v[1], a0.v[2], a0.v[3], a1.v[0], a1.v[1], a1.v[2], a1.v[3], a2.v[0], a2.v[1],
-                           a2.v[2], a2.v[3], a3.v[0], a3.v[1], a3.v[2], a3.v[3], a4.v[0], a4.v[1], a4.v[2], a4.v[3]};
+      // horizontal 13-tap blur of 4 adjacent outputs on packed fp32 FMAs (v_pk_fma_f32: two taps per
+      // instruction).  x[2p], x[2p+1] sit in an aligned register pair xp[p]; output i reads taps x[i+2 .. i+14],
+      // so even outputs pair the weights as (b0,b1)(b2,b3).. + b12 and odd outputs as b0 + (b1,b2)(b3,b4)..
+      const v4f* row = reinterpret_cast<const v4f*>(&s_m[c][4 * j - 8]);
+      const v4f a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3], a4 = row[4];
+      const v2f xp[10] = {a0.xy, a0.zw, a1.xy, a1.zw, a2.xy, a2.zw, a3.xy, a3.zw, a4.xy, a4.zw};
       float h[4];
+      {
+        v2f s0 = be[0] * xp[1], s1 = bo[0] * xp[2], s2 = be[0] * xp[2], s3 = bo[0] * xp[3];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {                   // output column 4j+i: taps at x[i+2 .. i+14]
-        float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < B4_BW; ++k) s += a.blur[k] * x[i + 2 + k];
-        h[i] = s;
+        for (int m = 1; m < 6; ++m) {
+          s0 += be[m] * xp[1 + m]; s1 += bo[m] * xp[2 + m]; s2 += be[m] * xp[2 + m]; s3 += bo[m] * xp[3 + m];
+        }
+        h[0] = (s0.x + b12 * xp[7].x) + s0.y;
+        h[1] = (s1.x + b0 * xp[1].y) + s1.y;
+        h[2] = (s2.x + b12 * xp[8].x) + s2.y;
+        h[3] = (s3.x + b0 * xp[2].y) + s3.y;
       }
       float v[4];
       const int slot = (r - (ys - B4_R)) % B4_BW;          // wave-uniform
-      win0[slot] = h[0]; win1[slot] = h[1]; win2[slot] = h[2]; win3[slot] = h[3];
+      winA[2 * slot] = h[0]; winA[2 * slot + 1] = h[1]; winB[2 * slot] = h[2]; winB[2 * slot + 1] = h[3];
       // weight of slot s when the newest row sits in `slot`: window position j = (s - slot - 1) mod 13 -> wr[]
-      // is kept rotated so that wr[s] is exactly that weight
+      // is kept rotated so that wr[s] is exactly that weight; columns (0,1) and (2,3) share one packed FMA
       {
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        v2f va = 0.0f, vb = 0.0f;
 #pragma unroll
         for (int sdx = 0; sdx < B4_BW; ++sdx) {
-          a0 += wr[sdx] * win0[sdx]; a1 += wr[sdx] * win1[sdx]; a2 += wr[sdx] * win2[sdx]; a3 += wr[sdx] * win3[sdx];
+          const v2f wa = {winA[2 * sdx], winA[2 * sdx + 1]}, wb = {winB[2 * sdx], winB[2 * sdx + 1]};
+          const v2f ww = {wr[sdx], wr[sdx]};
+          va += ww * wa; vb += ww * wb;
         }
-        v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
+        v[0] = va.x; v[1] = va.y; v[2] = vb.x; v[3] = vb.y;
       }
       if (yc >= ys) {
         float Mq[4];
@@ -290,11 +301,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
       for (int k = B4_BW - 1; k > 0; --k) wr[k] = wr[k - 1];
       wr[0] = last;
     }
-    if (more) {
-      stage1_finish(rn);
-      pT = nT;
-      pR = nR;
-    }
+    if (more) stage1_finish(rn);
     __syncthreads();
   }
   // ---- epilogue: pooling stage of the last centre row

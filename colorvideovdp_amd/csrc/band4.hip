@@ -12,10 +12,11 @@
 // the second phase of row r, behind ~100 FMAs of blur, so HBM latency is off the critical path:
 //
 //   phase 1:  pooling stage of the row finished last iteration (reads s_q of all channels, s_d)
-//             contrast/CSF stage of row r (reads s_ve, writes s_m and the s_d ring)
+//             contrast/CSF stage of row r (reads s_ve, s_lum; writes s_m and the s_d ring)
 //   barrier
 //   phase 2:  13-tap horizontal blur (5 ds_read_b128), 13-row register window, vertical blur,
-//             Mq = safe_pow(blur*10^mask_c, q_c) -> s_q ; vertical expand of row r+1 -> s_ve ; prefetch g
+//             Mq = safe_pow(blur*10^mask_c, q_c) -> s_q ; luminance terms of row r+1 -> s_lum ;
+//             vertical expand of row r+1 (r+2 for the luminance planes) -> s_ve ; prefetch g
 //   barrier
 //
 // Image-edge halo columns are produced by the in-image lanes as mirrored LDS writes (reflect padding
@@ -55,11 +56,14 @@ __device__ __forceinline__ int refl(int i, int n) {
 template <int NCH>
 __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   constexpr int NP = 2 * NCH;
-  __shared__ __attribute__((aligned(16))) float2 s_ve[NP][B4_VE / 2];   // float2 rows: guaranteed 8-byte aligned ds_read_b64
+  // s_ve is a ring of two rows (row parity): the luminance planes (0, 1; wave 0) run TWO rows ahead so that all
+  // waves can derive the per-column luminance terms of row r+1 (s_lum) during phase 2 of row r.
+  __shared__ __attribute__((aligned(16))) float2 s_ve[2][NP][B4_VE / 2];   // float2 rows: guaranteed 8-byte aligned ds_read_b64
+  __shared__ __attribute__((aligned(16))) float s_lum[4][256];             // 1/L_T, 1/L_R, CSF-LUT fraction, LUT byte offset
   __shared__ __attribute__((aligned(16))) float s_m[NCH][256];
   __shared__ __attribute__((aligned(16))) float s_q[NCH][256];
   __shared__ __attribute__((aligned(16))) float s_d[B4_R + 1][NCH][256];
-  __shared__ float s_lut[NCH][CVVDP_CSF_NODES];
+  __shared__ float s_lut[NCH][CVVDP_CSF_NODES + 1];                         // [32] = [31]: lerp partner of the last node
 
   const int t = threadIdx.x;
   const int c = t >> 6, j = t & 63;                 // channel (wave), lane
@@ -82,11 +86,13 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   const int vcx = cb + 4 * vch;                                    // first coarse column of the chunk
   const float* gcp = a.gc + (int64_t)item * Pc + vp * gcps;
 
-  for (int i = t; i < NCH * CVVDP_CSF_NODES; i += 64 * NCH) {
-    const int cc = i / CVVDP_CSF_NODES;
+  for (int i = t; i < NCH * (CVVDP_CSF_NODES + 1); i += 64 * NCH) {
+    const int cc = i / (CVVDP_CSF_NODES + 1), k = min(i - cc * (CVVDP_CSF_NODES + 1), CVVDP_CSF_NODES - 1);
     // log2-domain CSF row with the constant gains folded in: S*ch_gain*band_mul = 2^(lut*log2(10) + log2(sens_mul*ch_gain*band_mul))
-    s_lut[cc][i - cc * CVVDP_CSF_NODES] = a.lut[i] * kLog2_10 + fast_log2(a.sens_mul * a.ch_gain[cc] * a.band_mul);
+    s_lut[cc][i - cc * (CVVDP_CSF_NODES + 1)] = a.lut[cc * CVVDP_CSF_NODES + k] * kLog2_10 + fast_log2(a.sens_mul * a.ch_gain[cc] * a.band_mul);
   }
+  for (int i = t; i < 2 * NP * (B4_VE / 2); i += 64 * NCH) (&s_ve[0][0][0])[i] = make_float2(0.0f, 0.0f);   // unwritten apron elements
+  __syncthreads();
   const float e0 = a.kx[0], e1 = a.kx[1], eo = a.kx[2];
   const float ind_scale = (float)(CVVDP_CSF_NODES - 1) / (a.logL_last - a.logL_first);
   const float qc = a.q[c], eps_qc = a.eps_q[c];
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     cB = *reinterpret_cast<const float4*>(gcp + (int64_t)my * Wc + cx);
     cC = *reinterpret_cast<const float4*>(gcp + (int64_t)yb * Wc + cx);
   };
-  auto stage1_finish = [&](int rr) {
+  auto stage1_finish = [&](int rr, int buf) {
     if (edge_block && (clampL || clampR)) {      // replicate column 0 / Wc-1 for chunks left / right of the image
       const float ra = clampL ? cA.x : cA.w, rb = clampL ? cB.x : cB.w, rc = clampL ? cC.x : cC.w;
       cA = make_float4(ra, ra, ra, ra); cB = make_float4(rb, rb, rb, rb); cC = make_float4(rc, rc, rc, rc);
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = m0[i] * e0 + m1[i] * e1 + m2[i] * e0;
     }
-    lds_write4(reinterpret_cast<float*>(&s_ve[vp][2 + 2 * vch]), o);
+    lds_write4(reinterpret_cast<float*>(&s_ve[buf][vp][2 + 2 * vch]), o);
   };
 
   // horizontal half of the expand for this lane's 4 columns from 4 coarse values (lpyr_dec.py:234-237)
@@ -133,6 +139,30 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     ex[1] = B * eo + C * eo;
     ex[2] = B * e0 + C * e1 + D * e0;
     ex[3] = C * eo + D * eo;
+  };
+
+  // Per-column luminance terms of one row, shared by all channels (lpyr_dec.py:394,:408; interp.py:93): every
+  // thread expands the luminance planes for ONE column (blocks of 64*NCH columns) and publishes 1/L_T, 1/L_R,
+  // the LUT interpolation fraction and the LUT byte offset, so each channel wave spends 1 SFU op per pixel
+  // on the CSF instead of 4.  Element 4+i of an s_ve row is coarse column cb+i; fine column col -> 4+(col>>1).
+  const bool lodd = t & 1;                           // 64*NCH is even: a thread's columns keep their parity
+  const float lwa = lodd ? 0.0f : e0, lwb = lodd ? eo : e1, lwc = lodd ? eo : e0;
+  auto lum_prep = [&](int buf) {
+    const float* yT = reinterpret_cast<const float*>(&s_ve[buf][0][0]);
+    const float* yR = reinterpret_cast<const float*>(&s_ve[buf][1][0]);
+    for (int col = t; col < 256; col += 64 * NCH) {
+      const int e = 4 + (col >> 1);
+      const float eyT = yT[e - 1] * lwa + yT[e] * lwb + yT[e + 1] * lwc;
+      const float eyR = yR[e - 1] * lwa + yR[e] * lwb + yR[e + 1] * lwc;
+      const float Lt = fmaxf(eyT, 0.01f), Lr = fmaxf(eyR, 0.01f);              // lpyr_dec.py:394
+      float ind = (fast_log2(Lr) * kLog10_2 - a.logL_first) * ind_scale;       // lpyr_dec.py:408, interp.py:93
+      ind = fminf(fmaxf(ind, 0.0f), (float)(CVVDP_CSF_NODES - 1));
+      const int i0 = (int)ind;
+      s_lum[0][col] = fast_rcp(Lt);
+      s_lum[1][col] = fast_rcp(Lr);
+      s_lum[2][col] = ind - (float)i0;
+      s_lum[3][col] = __int_as_float(i0 * 4);
+    }
   };
 
   // Vertical-blur window: slot s of column i holds one horizontally blurred row.  The newest row is written
@@ -171,16 +201,32 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
         make_float4(D[0], D[1], D[2], D[3]);
   };
 
-  // ---- prologue: expand row and g prefetch for the first row
+  // ---- prologue: expand rows (luminance: two of them), g prefetch and luminance terms for the first row
+  const int ahead = c == 0 ? 2 : 1;                  // wave-uniform
   int r = ys - B4_R;
   int rr = refl(r, H);
   stage1_load(rr);
   float4 pT = make_float4(0, 0, 0, 0), pR = make_float4(0, 0, 0, 0);
-  if (in_img) {
-    pT = ld_stream4(gT + (int64_t)rr * W + fc0);
-    pR = ld_stream4(gR + (int64_t)rr * W + fc0);
+  // g rows are streamed from HBM two rows ahead.  Every lane issues every load (out-of-image halo lanes and
+  // rows past the segment read a clamped, valid address) so that each iteration has the same five loads in
+  // flight and the waits can be exact vmcnt(N) counts instead of a full drain.
+  const int fcl = min(max(fc0, 0), W - 4);
+  float4 nT, nR;
+  {
+    pT = ld_stream4(gT + (int64_t)rr * W + fcl);
+    pR = ld_stream4(gR + (int64_t)rr * W + fcl);
+    const int r1 = refl(r + 1, H);
+    nT = ld_stream4(gT + (int64_t)r1 * W + fcl);
+    nR = ld_stream4(gR + (int64_t)r1 * W + fcl);
   }
-  stage1_finish(rr);
+  stage1_finish(rr, r & 1);
+  if (c == 0) {
+    const int r1 = refl(r + 1, H);
+    stage1_load(r1);
+    stage1_finish(r1, (r + 1) & 1);
+  }
+  __syncthreads();
+  lum_prep(r & 1);
   __syncthreads();
 
   for (; r < ye + B4_R; ++r) {
@@ -190,35 +236,21 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     float m[4], d[4];
     if (in_img) {
       float exT[4], exR[4];
-      expand4(s_ve[2 * c], exT);
-      expand4(s_ve[2 * c + 1], exR);
+      expand4(s_ve[r & 1][2 * c], exT);
+      expand4(s_ve[r & 1][2 * c + 1], exR);
+      const f4 rLt = lds_read4(&s_lum[0][4 * j]), rLr = lds_read4(&s_lum[1][4 * j]), fr = lds_read4(&s_lum[2][4 * j]);
+      const f4 lo = lds_read4(&s_lum[3][4 * j]);
       const float gt[4] = {pT.x, pT.y, pT.z, pT.w}, gr[4] = {pR.x, pR.y, pR.z, pR.w};
-      auto contrast = [&](const float (&eyT)[4], const float (&eyR)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float Lt = fmaxf(eyT[i], 0.01f), Lr = fmaxf(eyR[i], 0.01f);      // lpyr_dec.py:394
-          const float rLt = fast_rcp(Lt), rLr = fast_rcp(Lr);
-          float ind = (fast_log2(Lr) * kLog10_2 - a.logL_first) * ind_scale;     // lpyr_dec.py:408, interp.py:93
-          ind = fminf(fmaxf(ind, 0.0f), (float)(CVVDP_CSF_NODES - 1));
-          const int i0 = (int)ind;
-          const float fr = ind - (float)i0;
-          const int i1 = min(i0 + 1, CVVDP_CSF_NODES - 1);
-          const float l0 = s_lut[c][i0], l1 = s_lut[c][i1];
-          const float S = fast_exp2(l0 + (l1 - l0) * fr);                        // csf.py:49, cvvdp_metric.py:709,:836
-          const float ct = fminf((gt[i] - exT[i]) * rLt, 1000.0f);               // lpyr_dec.py:402 (band gain :66 is in S)
-          const float cr = fminf((gr[i] - exR[i]) * rLr, 1000.0f);
-          const float Tp = ct * S, Rp = cr * S;
-          m[i] = fminf(fabsf(Tp), fabsf(Rp));                                    // cvvdp_metric.py:845
-          d[i] = fabsf(Tp - Rp);
-        }
-      };
-      if (c == 0) {                                   // wave-uniform: the luminance planes are this wave's own
-        contrast(exT, exR);
-      } else {
-        float eyT[4], eyR[4];
-        expand4(s_ve[0], eyT);
-        expand4(s_ve[1], eyR);
-        contrast(eyT, eyR);
+      for (int i = 0; i < 4; ++i) {
+        const float* lp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(&s_lut[c][0]) + __float_as_int(lo.v[i]));
+        const float l0 = lp[0], l1 = lp[1];
+        const float S = fast_exp2(l0 + (l1 - l0) * fr.v[i]);                     // csf.py:49, cvvdp_metric.py:709,:836
+        const float ct = fminf((gt[i] - exT[i]) * rLt.v[i], 1000.0f);            // lpyr_dec.py:402 (band gain :66 is in S)
+        const float cr = fminf((gr[i] - exR[i]) * rLr.v[i], 1000.0f);
+        const float Tp = ct * S, Rp = cr * S;
+        m[i] = fminf(fabsf(Tp), fabsf(Rp));                                      // cvvdp_metric.py:845
+        d[i] = fabsf(Tp - Rp);
       }
       lds_write4(&s_m[c][4 * j], m);
       const int ds = ((r % (B4_R + 1)) + (B4_R + 1)) % (B4_R + 1);
@@ -242,17 +274,18 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     }
     __syncthreads();
     // ================= phase 2
-    // issue next row's global loads right after the barrier; they are consumed at the end of this phase
-    // (coarse rows -> s_ve) and in the next phase 1 (g), i.e. behind the ~120 FMAs of the blur
+    // issue the global loads right after the barrier: coarse rows are consumed at the end of this phase
+    // (-> s_ve), the g rows a whole iteration later
     const bool more = r + 1 < ye + B4_R;
-    const int rn = refl(r + 1, H);
-    if (more) {
-      stage1_load(rn);
-      if (in_img) {                                   // pT / pR were consumed in phase 1: reload in place
-        pT = ld_stream4(gT + (int64_t)rn * W + fc0);
-        pR = ld_stream4(gR + (int64_t)rn * W + fc0);
-      }
+    const int rs = min(refl(r + ahead, H), H - 1);
+    stage1_load(rs);
+    pT = nT; pR = nR;                                 // row r+1, requested a whole iteration ago
+    {
+      const int r2 = min(refl(r + 2, H), H - 1);
+      nT = ld_stream4(gT + (int64_t)r2 * W + fcl);
+      nR = ld_stream4(gR + (int64_t)r2 * W + fcl);
     }
+    if (more) lum_prep((r + 1) & 1);                  // luminance planes of row r+1 were published an iteration ago
     const int yc = r - B4_R;
     if (interior) {
       // horizontal 13-tap blur of 4 adjacent outputs on packed fp32 FMAs (v_pk_fma_f32: two taps per
@@ -301,7 +334,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
       for (int k = B4_BW - 1; k > 0; --k) wr[k] = wr[k - 1];
       wr[0] = last;
     }
-    if (more) stage1_finish(rn);
+    stage1_finish(rs, (r + ahead) & 1);
     __syncthreads();
   }
   // ---- epilogue: pooling stage of the last centre row

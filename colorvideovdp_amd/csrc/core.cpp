@@ -399,7 +399,9 @@ int cvvdp_process_block(cvvdp_handle* h, const void* t, const void* r, int32_t d
   const int64_t P0 = h->lv[0].P;
   f.src[0] = t; f.src[1] = r;
   const int64_t* S[2] = {st, sr};
-  for (int k = 0; k < 2; ++k) { f.sb[k] = S[k][0]; f.sc[k] = S[k][1]; f.sf[k] = S[k][2]; f.sh[k] = S[k][3]; f.sw[k] = S[k][4]; }
+  // 1-channel clips broadcast Y into the three colour planes (cvvdp_metric.py:464-465): a zero channel stride makes
+  // the FIR kernels read the same sample three times instead of branching (a fixed number of loads per frame)
+  for (int k = 0; k < 2; ++k) { f.sb[k] = S[k][0]; f.sc[k] = c.channels == 3 ? S[k][1] : 0; f.sf[k] = S[k][2]; f.sh[k] = S[k][3]; f.sw[k] = S[k][4]; }
   f.dtype = dtype;
   fill_display(h, f.dm);
   f.W = c.width; f.P = (int)P0; f.batch = c.batch; f.n_frames = n_frames; f.fl = fl;
@@ -416,6 +418,13 @@ int cvvdp_process_block(cvvdp_handle* h, const void* t, const void* r, int32_t d
   for (int ch = 0; ch < 4; ++ch)
     for (int k = 0; k < std::min(2 * fl, CVVDP_MAX_FILTER_LEN); ++k)   // F.flip(0) (:556), written twice back to back so
       f.taps[ch * CVVDP_MAX_FILTER_LEN + k] = c.taps[ch * CVVDP_MAX_FILTER_LEN + (fl - 1 - (k % fl))];   // that a rotated view is contiguous
+  if (fl >= 3 && fl <= 17) {                   // rotating-window kernel: taps of positions 0..fl-2 twice, newest at [32]
+    const int M = fl - 1;
+    for (int ch = 0; ch < 4; ++ch) {
+      for (int i = 0; i < 2 * M; ++i) f.taps_rot[ch * CVVDP_ROT_TAPS + i] = c.taps[ch * CVVDP_MAX_FILTER_LEN + (fl - 1 - (i % M))];
+      f.taps_rot[ch * CVVDP_ROT_TAPS + 32] = c.taps[ch * CVVDP_MAX_FILTER_LEN + 0];   // position fl-1 (newest) <- F[0]
+    }
+  }
   for (int k = 0; k < fl - 1; ++k) {
     const int e = hist_src[k];
     if (e >= 32767 || e < -(fl - 1)) return fail(h, CVVDP_E_ARG, "hist_src[%d] = %d out of range", k, e);

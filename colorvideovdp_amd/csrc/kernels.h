@@ -44,6 +44,7 @@ struct PhotoArgs {
 void launch_photometry(const PhotoArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- temporal FIR (K1)
+constexpr int CVVDP_ROT_TAPS = 40;
 struct FirArgs {
   const void* src[2];      // raw test / reference frames handed to this block
   int64_t sb[2], sc[2], sf[2], sh[2], sw[2];  // element strides (B, C, F, H, W)
@@ -58,6 +59,7 @@ struct FirArgs {
   float* out;              // level-0 planes [plane][item][P]
   int64_t o_plane;         // items_cap * P
   float taps[4 * CVVDP_MAX_FILTER_LEN];     // flipped: taps[c][k] multiplies window position k
+  float taps_rot[4 * 40];                   // k_fir_rot: [c][i < 2(fl-1)] = weight of window position i mod (fl-1), [c][32] = newest
   int16_t hist_src[CVVDP_MAX_FILTER_LEN];   // window position k < fl-1: >= 0 raw frame index, < 0 history slot -1-e
 };
 void launch_fir(const FirArgs& a, float* hist_shadow, hipStream_t s);

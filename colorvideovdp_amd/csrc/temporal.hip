@@ -24,14 +24,8 @@ namespace cvvdp {
 template <int DT, int V>
 __device__ __forceinline__ void load_pixels(const FirArgs& a, int side, int64_t off, float (&in)[3][V]) {
   const void* src = a.src[side];
-  if (a.dm.channels == 3) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) load_run<DT, V>(src, off + c * a.sc[side], in[c]);
-  } else {
-    load_run<DT, V>(src, off, in[0]);
-#pragma unroll
-    for (int i = 0; i < V; ++i) in[1][i] = in[2][i] = in[0][i];
-  }
+  for (int c = 0; c < 3; ++c) load_run<DT, V>(src, off + c * a.sc[side], in[c]);   // sc == 0 for 1-channel clips
 }
 
 template <int DT, int V>
@@ -175,7 +169,7 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
 // the window costs 51 VGPRs: 5-6 waves per SIMD hide the HBM latency this kernel is bound by.
 template <int DT, int FL>
 __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
-  static_assert(FL <= 17, "window = one 16-wide register vector (+1 scalar slot)");
+  static_assert(FL >= 3 && FL <= 17, "window = one 16-wide register vector + the newest frame in a scalar slot");
   typedef float v16f __attribute__((ext_vector_type(16)));
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= a.P) return;
@@ -185,22 +179,19 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
   const int64_t sf = a.sf[side];
   float* hist = a.hist + side * a.h_side + b * a.h_b + pix;
 
-  v16f wlo[3];          // slots 0..15
-  float whi[3];         // slot 16
-  auto put = [&](int slot, const float (&d)[3][1]) {   // slot is wave-uniform
-    if (FL <= 16 || slot < 16) {
-#pragma unroll
-      for (int p = 0; p < 3; ++p) wlo[p][slot] = d[p][0];
-    } else {
-#pragma unroll
-      for (int p = 0; p < 3; ++p) whi[p] = d[p][0];
-    }
-  };
-  // Slot of a frame = its clip index mod FL, so the order in which a frame's 17 products are summed does not
-  // depend on how the clip is cut into blocks or shards (bit-identical results for any blocking).
-  int slot = ((a.abs_first - (FL - 1)) % FL + FL) % FL;     // slot of window position 0 of the first scored frame
-  // ---- prologue: window positions 0..FL-2
-  for (int k = 0; k < FL - 1; ++k) {
+  // Window of frame A = frames A-M..A (M = FL-1).  The newest frame lives in a scalar register per plane (whi), the M
+  // older ones in one register vector per plane: frame B sits in slot B mod M and is written there -- by an
+  // M0-relative move, the slot is wave-uniform -- one step after it arrived, replacing frame B-M.  The data never
+  // moves again; the taps rotate instead: slot s holds window position (s - A) mod M, whose weight is read from a
+  // doubled table at offset (M - A mod M) mod M.  Slots are keyed to the CLIP index of a frame, so the order in which a
+  // frame's FL products are summed does not depend on how the clip is cut into blocks or shards (bit-identical
+  // results for any blocking), and the loop body has no data-dependent control flow.
+  constexpr int M = FL - 1;
+  v16f wlo[3];
+  float whi[3];
+  int sA = ((a.abs_first % M) + M) % M;               // A mod M for the frame about to be processed
+  // ---- prologue: window positions 0..M-1 of the first frame = frames A0-M .. A0-1
+  for (int k = 0; k < M; ++k) {
     const int e = a.hist_src[k];
     float d[3][1];
     if (e >= 0) {
@@ -210,48 +201,62 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
     } else {
       for (int p = 0; p < 3; ++p) d[p][0] = hist[p * a.h_plane + (int64_t)(-1 - e) * a.h_slot];
     }
-    put(slot, d);
-    slot = (slot + 1 == FL) ? 0 : slot + 1;
+    if (k < M - 1) {
+      const int sl = __builtin_amdgcn_readfirstlane((sA + k) % M);   // frame A0-M+k -> slot (A0+k) mod M
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wlo[p][sl] = d[p][0];
+    } else {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) whi[p] = d[p][0];    // frame A0-1
+    }
   }
   float* out = a.out + (int64_t)b * a.P + pix;
   const int64_t o_item = (int64_t)a.batch * a.P;
-  constexpr int PF = CVVDP_FIR_PF;
+  constexpr int PF = 4;
   float pf[PF][3][1];
 #pragma unroll
   for (int q = 0; q < PF; ++q)
-    if (q < a.n_frames) load_pixels<DT, 1>(a, side, off0 + (int64_t)(a.raw_first + q) * sf, pf[q]);
-  // `slot` is now where the next frame is written; window position k then sits in slot (slot+1+k) % FL
-  for (int fi = 0; fi < a.n_frames; ++fi) {
-    float d[3][1];
-    convert_pixels<DT, 1>(a, pf[0], d);
-#pragma unroll
-    for (int q = 0; q + 1 < PF; ++q)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) pf[q][p][0] = pf[q + 1][p][0];
-    if (fi + PF < a.n_frames) load_pixels<DT, 1>(a, side, off0 + (int64_t)(a.raw_first + fi + PF) * sf, pf[PF - 1]);
-    put(slot, d);
-    // slot s holds window position (s - slot - 1) mod FL: its weight is taps2[c][FL - 1 - slot + s], taps2 = taps ++ taps
-    const float* tb = a.taps + (FL - 1 - slot);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {     // Y-sust, RG, YV, Y-trans (window of plane 0 again), cvvdp_metric.py:554-560
-      const int p = (c == 3) ? 0 : c;
-      const float* t = tb + c * CVVDP_MAX_FILTER_LEN;
-      float acc = 0.0f;
-#pragma unroll
-      for (int s = 0; s < (FL < 16 ? FL : 16); ++s) acc += wlo[p][s] * t[s];
-      if constexpr (FL == 17) acc += whi[p] * t[16];
-      __builtin_nontemporal_store(acc, &out[(int64_t)(2 * c + side) * a.o_plane + (int64_t)fi * o_item]);   // streamed once, read by later kernels
-    }
-    slot = (slot + 1 == FL) ? 0 : slot + 1;
+    load_pixels<DT, 1>(a, side, off0 + (int64_t)(a.raw_first + min(q, a.n_frames - 1)) * sf, pf[q]);
+  // One frame: convert prefetch slot Q, refill it with frame fi+PF, FIR, store.  The refill is unconditional (the
+  // last PF frames re-read the last frame) and the frame loop is unrolled PF times with static prefetch slots, so
+  // no register copies touch values still in flight and the compiler can wait with exact vmcnt(N) counts.
+#define CVVDP_FIR_FRAME(FI, Q)                                                                                   \
+  {                                                                                                              \
+    float d[3][1];                                                                                               \
+    convert_pixels<DT, 1>(a, pf[Q], d);                                                                          \
+    load_pixels<DT, 1>(a, side, off0 + (int64_t)(a.raw_first + min((FI) + PF, a.n_frames - 1)) * sf, pf[Q]);    \
+    const int sw = __builtin_amdgcn_readfirstlane(sA == 0 ? M - 1 : sA - 1);   /* (A-1) mod M, in an SGPR */      \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p) { wlo[p][sw] = whi[p]; whi[p] = d[p][0]; }                     \
+    const float* tb = a.taps_rot + (sA == 0 ? 0 : M - sA);                                                       \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) { /* Y-sust, RG, YV, Y-trans (plane 0 again), cvvdp_metric.py:554-560 */ \
+      const int p = (c == 3) ? 0 : c;                                                                            \
+      const float* t = tb + c * CVVDP_ROT_TAPS;                                                                  \
+      float acc = 0.0f;                                                                                          \
+      _Pragma("unroll") for (int s = 0; s < M; ++s) acc += wlo[p][s] * t[s];                                     \
+      acc += whi[p] * a.taps_rot[c * CVVDP_ROT_TAPS + 32];                                                       \
+      __builtin_nontemporal_store(acc, &out[(int64_t)(2 * c + side) * a.o_plane + (int64_t)(FI) * o_item]);     \
+    }                                                                                                            \
+    sA = (sA + 1 == M) ? 0 : sA + 1;                                                                             \
   }
-  // ---- epilogue: the last FL-1 frames in time order: window positions 1..FL-1 of the last frame's window;
-  // after the loop `slot` is the slot of the OLDEST entry, so position k (k >= 1) sits in slot (slot + k) % FL
-  if (a.write_hist) {
-    for (int k = 0; k < FL - 1; ++k) {
-      const int s = (slot + 1 + k) % FL;     // uniform
+  int fi = 0;
+  for (; fi + PF <= a.n_frames; fi += PF) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) hist[p * a.h_plane + (int64_t)k * a.h_slot] = (FL <= 16 || s < 16) ? wlo[p][s] : whi[p];
+    for (int u = 0; u < PF; ++u) CVVDP_FIR_FRAME(fi + u, u)
+  }
+#pragma unroll
+  for (int u = 0; u + 1 < PF; ++u)                    // remainder: slots 0.. hold frames fi.. in order
+    if (fi + u < a.n_frames) CVVDP_FIR_FRAME(fi + u, u)
+#undef CVVDP_FIR_FRAME
+  // ---- epilogue: the last M frames in time order = window positions 1..M of the last frame's window: position k < M
+  // sits in slot (A_last + k) mod M = (sA - 1 + k) mod M (sA is already A_last + 1), position M is whi
+  if (a.write_hist) {
+    for (int k = 1; k < M; ++k) {
+      const int sl = __builtin_amdgcn_readfirstlane((sA + M - 1 + k) % M);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) hist[p * a.h_plane + (int64_t)(k - 1) * a.h_slot] = wlo[p][sl];
     }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) hist[p * a.h_plane + (int64_t)(M - 1) * a.h_slot] = whi[p];
   }
 }
 

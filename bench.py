@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the ColorVideoVDP hot path on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload 4k64|fhd64|4k256] [--dtype f32|u8]
+    python bench.py [--gpus N --steps K --warmup W] [--workload 4k64|fhd64|4k256] [--dtype f32|u8|yuv420p8|yuv420p10]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one full predict() of the workload clip pair (display model -> DKL -> temporal FIR ->
@@ -30,7 +30,8 @@ WORKLOADS = {
     "4k256": (3840, 2160, 256, 60, "standard_4k"),    # configs[2]
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
-PATH_BYTES_PER_PIXEL = {"f32": 211.0, "u8": 193.0}   # SURVEY.md 8(d) whole-path algorithmic bytes
+PATH_BYTES_PER_PIXEL = {"f32": 211.0, "u8": 193.0,   # SURVEY.md 8(d) whole-path algorithmic bytes
+                        "yuv420p8": 190.0, "yuv420p10": 193.0}   # same model with 3 / 6 input bytes per pixel pair
 BAND0_BYTES_PER_PIXEL = 40.0   # level-0 band kernel: reads g0 (8 planes x 4 B) + g1 (8 x 4 / 4)
 
 
@@ -87,6 +88,46 @@ class ResidentClip:
         return self.test[:, :, a - self.lo:b - self.lo], self.ref[:, :, a - self.lo:b - self.lo], self.code
 
 
+class ResidentYuvClip:
+    """Planar Y'CbCr 4:2:0 clip (BT.709, limited range, 8 or 10 bit) resident in HBM, laid out exactly like a .yuv file
+    (frame = Y plane, U plane, V plane); implements the raw-block hook of colorvideovdp_amd.video_source_yuv_file.
+    Made from the same synthetic frames as ResidentClip (BT.709 forward matrix, 2x2 box chroma)."""
+
+    def __init__(self, n_total, lo, hi, H, W, fps, bit_depth, device):
+        from colorvideovdp_amd import _capi
+        self.n_total, self.lo, self.hi, self.H, self.W, self.fps = n_total, lo, hi, H, W, fps
+        self.dm_photometry = None
+        self.frame = H * W + 2 * (H // 2) * (W // 2)
+        tdt = torch.uint8 if bit_depth == 8 else torch.int16
+        self.bufs = [torch.empty((hi - lo) * self.frame, dtype=tdt, device=device) for _ in range(2)]
+        s = float(2 ** (bit_depth - 8))
+        for f in range(lo, hi):
+            for k, rgb in enumerate(synth_frame(f, H, W, device)):
+                rgb = rgb.float() / 255
+                Y = 0.2126 * rgb[0] + 0.7152 * rgb[1] + 0.0722 * rgb[2]
+                cb, cr = (rgb[2] - Y) / 1.8556, (rgb[0] - Y) / 1.5748
+                c2 = torch.nn.functional.avg_pool2d(torch.stack([cb, cr])[None], 2)[0]
+                codes = torch.cat([(16 + 219 * Y).flatten(), (128 + 224 * c2[0]).flatten(), (128 + 224 * c2[1]).flatten()])
+                self.bufs[k][(f - lo) * self.frame:(f - lo + 1) * self.frame] = torch.round(codes * s).to(tdt)
+        self.fmt = _capi.YuvFormat()
+        self.fmt.chroma, self.fmt.bit_depth, self.fmt.matrix = 420, bit_depth, 709
+        self.fmt.frame_stride_test = self.fmt.frame_stride_ref = self.frame
+
+    def get_video_size(self):
+        return (self.H, self.W, self.n_total)
+
+    def get_frames_per_second(self):
+        return self.fps
+
+    def get_batch_size(self):
+        return 1
+
+    def get_raw_yuv_block(self, a, b, device):
+        assert self.lo <= a and b <= self.hi, (a, b, self.lo, self.hi)
+        sl = slice((a - self.lo) * self.frame, (b - self.lo) * self.frame)
+        return self.bufs[0][sl], self.bufs[1][sl], self.fmt
+
+
 def cpu_baseline(W, H, fps, display, n_frames):
     """Oracle ('port' of the reference's torch-CPU path) on the first n_frames of the same synthetic clip."""
     from oracle import cvvdp_oracle as orc
@@ -108,7 +149,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="4k64", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="f32", choices=["f32", "u8"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "u8", "yuv420p8", "yuv420p10"])
     ap.add_argument("--block-frames", type=int, default=None)
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
@@ -134,7 +175,10 @@ def main():
     m = cv.cvvdp(display_name=display, device=device, block_frames=args.block_frames)
     fl = int(np.ceil(0.250 * fps / 2) * 2) + 1   # cvvdp_metric.py:1059
     lo = max(0, first - (fl - 1))
-    clip = ResidentClip(n_total, lo, first + count, H, W, fps, args.dtype, device)
+    if args.dtype.startswith("yuv"):
+        clip = ResidentYuvClip(n_total, lo, first + count, H, W, fps, 8 if args.dtype.endswith("p8") else 10, device)
+    else:
+        clip = ResidentClip(n_total, lo, first + count, H, W, fps, args.dtype, device)
     if world > 1:
         m.set_frame_sharding("world")
 

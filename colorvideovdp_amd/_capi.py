@@ -12,9 +12,9 @@ MAX_WINDOW = 256
 CSF_NODES = 32
 PROF_N = 6
 PROF_NAMES = ("photometry", "temporal_fir", "pyr_reduce", "band_level0", "band_rest", "heatmap")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
-U8, U16, F16, F32, F32_DKL = range(5)
+U8, U16, F16, F32, F32_DKL, YUV8, YUV16 = range(7)
 HEATMAP = {None: 0, "none": 0, "raw": 1, "threshold": 2, "supra-threshold": 3}
 BUF_HIST, BUF_GPYR, BUF_DDUMP, BUF_HEAT, BUF_Q = range(5)
 
@@ -59,6 +59,13 @@ class Clip(C.Structure):
     ]
 
 
+class YuvFormat(C.Structure):
+    _fields_ = [
+        ("chroma", C.c_int32), ("bit_depth", C.c_int32), ("matrix", C.c_int32), ("reserved", C.c_int32),
+        ("frame_stride_test", C.c_int64), ("frame_stride_ref", C.c_int64),
+    ]
+
+
 SYMBOLS = {
     "cvvdp_abi_version": (C.c_int, []),
     "cvvdp_struct_sizes": (None, [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -71,6 +78,8 @@ SYMBOLS = {
     "cvvdp_put_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
     "cvvdp_process_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                       C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p]),
+    "cvvdp_process_block_yuv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(YuvFormat), C.c_int32, C.POINTER(C.c_int32),
+                                          C.c_int32, C.c_int32, C.c_void_p]),
     "cvvdp_process_image": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cvvdp_get_q_per_ch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvvdp_pool_jod": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -383,13 +383,53 @@ int cvvdp_put_image(cvvdp_handle* h, const void* t, const void* r, int32_t dtype
   return check_launch(h, "photometry");
 }
 
+static int process_block_impl(cvvdp_handle* h, const void* t, const void* r, int32_t dtype, const int64_t st[5], const int64_t sr[5],
+                              const cvvdp::YuvArgs* yuv, int32_t raw_first, const int32_t* hist_src, int32_t n_frames,
+                              int32_t q_frame_offset, void* stream);
+
 int cvvdp_process_block(cvvdp_handle* h, const void* t, const void* r, int32_t dtype, const int64_t st[5], const int64_t sr[5],
                         int32_t raw_first, const int32_t* hist_src, int32_t n_frames, int32_t q_frame_offset, void* stream) {
+  if (h && (dtype < CVVDP_U8 || dtype > CVVDP_F32_DKL)) return fail(h, CVVDP_E_UNSUPPORTED, "dtype %d unsupported", dtype);
+  return process_block_impl(h, t, r, dtype, st, sr, nullptr, raw_first, hist_src, n_frames, q_frame_offset, stream);
+}
+
+int cvvdp_process_block_yuv(cvvdp_handle* h, const void* t, const void* r, const cvvdp_yuv_format* fmt, int32_t raw_first,
+                            const int32_t* hist_src, int32_t n_frames, int32_t q_frame_offset, void* stream) {
+  if (!h) return CVVDP_E_STATE;
+  if (!fmt) return fail(h, CVVDP_E_ARG, "format missing");
+  const cvvdp_clip& c = h->c;
+  if (c.channels != 3 || c.batch != 1) return fail(h, CVVDP_E_ARG, "Y'CbCr input needs a clip configured with 3 channels and batch 1");
+  if (fmt->bit_depth < 8 || fmt->bit_depth > 16) return fail(h, CVVDP_E_UNSUPPORTED, "bit depth %d unsupported", fmt->bit_depth);
+  if (fmt->matrix != 709 && fmt->matrix != 2020) return fail(h, CVVDP_E_UNSUPPORTED, "matrix %d unsupported (709 or 2020)", fmt->matrix);
+  const int W = c.width, H = c.height;
+  cvvdp::YuvArgs y{};
+  if (fmt->chroma == 444) { y.Wc = W; y.Hc = H; y.inv_fx = 1.0f; y.inv_fy = 1.0f; }
+  else if (fmt->chroma == 422) { y.Wc = W / 2; y.Hc = H; y.inv_fx = 0.5f; y.inv_fy = 1.0f; }
+  else if (fmt->chroma == 420) { y.Wc = W / 2; y.Hc = H / 2; y.inv_fx = 0.5f; y.inv_fy = 0.5f; }
+  else return fail(h, CVVDP_E_UNSUPPORTED, "chroma subsampling %d unsupported (420, 422, 444)", fmt->chroma);
+  if (fmt->chroma != 444 && (W % 2 || (fmt->chroma == 420 && H % 2)))
+    return fail(h, CVVDP_E_ARG, "%dx%d cannot be %d subsampled", W, H, fmt->chroma);
+  const int64_t frame = (int64_t)W * H + 2 * (int64_t)y.Wc * y.Hc;
+  if (fmt->frame_stride_test < frame || fmt->frame_stride_ref < frame) return fail(h, CVVDP_E_ARG, "frame stride shorter than a frame");
+  y.u_off = (int64_t)W * H; y.v_off = y.u_off + (int64_t)y.Wc * y.Hc;
+  // video_source_yuv.py:198-206: python-double constants, applied to fp32 tensors
+  const double sc = (double)(1 << (fmt->bit_depth - 8));
+  y.wy = (float)(1.0 / (sc * 219.0)); y.oy = (float)(16.0 / 219.0);
+  y.wc = (float)(1.0 / (sc * 224.0)); y.oc = (float)(128.0 / 224.0);
+  if (fmt->matrix == 2020) { y.rv = 1.47460f; y.gu = -0.16455f; y.gv = -0.57135f; y.bu = 1.88140f; }   // :151-154
+  else { y.rv = 1.402f; y.gu = -0.344136f; y.gv = -0.714136f; y.bu = 1.772f; }                          // :157-160
+  const int64_t st[5] = {0, 0, fmt->frame_stride_test, W, 1}, sr[5] = {0, 0, fmt->frame_stride_ref, W, 1};
+  return process_block_impl(h, t, r, fmt->bit_depth == 8 ? CVVDP_YUV8 : CVVDP_YUV16, st, sr, &y, raw_first, hist_src, n_frames,
+                            q_frame_offset, stream);
+}
+
+static int process_block_impl(cvvdp_handle* h, const void* t, const void* r, int32_t dtype, const int64_t st[5], const int64_t sr[5],
+                              const cvvdp::YuvArgs* yuv, int32_t raw_first, const int32_t* hist_src, int32_t n_frames,
+                              int32_t q_frame_offset, void* stream) {
   if (!h || !h->ws) return fail(h, CVVDP_E_STATE, "no workspace bound");
   const cvvdp_clip& c = h->c;
   if (!c.is_video) return fail(h, CVVDP_E_STATE, "configured for an image");
   if (!t || !r || !st || !sr || raw_first < 0) return fail(h, CVVDP_E_ARG, "bad frame arguments");
-  if (dtype < CVVDP_U8 || dtype > CVVDP_F32_DKL) return fail(h, CVVDP_E_UNSUPPORTED, "dtype %d unsupported", dtype);
   if (n_frames < 1 || n_frames > c.block_frames) return fail(h, CVVDP_E_ARG, "n_frames out of range");
   if (q_frame_offset < 0 || q_frame_offset + n_frames > c.n_frames) return fail(h, CVVDP_E_ARG, "frame offset out of range");
   const int fl = c.filter_len;
@@ -403,6 +443,7 @@ int cvvdp_process_block(cvvdp_handle* h, const void* t, const void* r, int32_t d
   // the FIR kernels read the same sample three times instead of branching (a fixed number of loads per frame)
   for (int k = 0; k < 2; ++k) { f.sb[k] = S[k][0]; f.sc[k] = c.channels == 3 ? S[k][1] : 0; f.sf[k] = S[k][2]; f.sh[k] = S[k][3]; f.sw[k] = S[k][4]; }
   f.dtype = dtype;
+  if (yuv) f.yuv = *yuv;
   fill_display(h, f.dm);
   f.W = c.width; f.P = (int)P0; f.batch = c.batch; f.n_frames = n_frames; f.fl = fl;
   f.raw_first = raw_first; f.write_hist = 1;

@@ -45,6 +45,13 @@ void launch_photometry(const PhotoArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- temporal FIR (K1)
 constexpr int CVVDP_ROT_TAPS = 40;
+struct YuvArgs {            // planar Y'CbCr sources (video_source_yuv.py:79-124, 147-223); frame = Y plane, U plane, V plane
+  int32_t Wc, Hc;           // chroma plane size
+  float inv_fx, inv_fy;     // 1 / up-sampling factor (1 or 0.5) per axis
+  int64_t u_off, v_off;     // sample offsets of the chroma planes inside a frame
+  float wy, oy, wc, oc;     // limited-range fixed point -> float: Y' = wy*code - oy, C = wc*code - oc
+  float rv, gu, gv, bu;     // R' = Y' + rv*Cr, G' = Y' + gu*Cb + gv*Cr, B' = Y' + bu*Cb
+};
 struct FirArgs {
   const void* src[2];      // raw test / reference frames handed to this block
   int64_t sb[2], sc[2], sf[2], sh[2], sw[2];  // element strides (B, C, F, H, W)
@@ -60,6 +67,7 @@ struct FirArgs {
   int64_t o_plane;         // items_cap * P
   float taps[4 * CVVDP_MAX_FILTER_LEN];     // flipped: taps[c][k] multiplies window position k
   float taps_rot[4 * 40];                   // k_fir_rot: [c][i < 2(fl-1)] = weight of window position i mod (fl-1), [c][32] = newest
+  YuvArgs yuv;                              // used by the CVVDP_YUV* dtypes only
   int16_t hist_src[CVVDP_MAX_FILTER_LEN];   // window position k < fl-1: >= 0 raw frame index, < 0 history slot -1-e
 };
 void launch_fir(const FirArgs& a, float* hist_shadow, hipStream_t s);

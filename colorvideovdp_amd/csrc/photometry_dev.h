@@ -143,6 +143,6 @@ inline bool can_vectorise(int V, int W, const int64_t* sb, const int64_t* sc, co
   return true;
 }
 
-inline int dtype_bytes(int dt) { return dt == CVVDP_U8 ? 1 : (dt == CVVDP_U16 || dt == CVVDP_F16) ? 2 : 4; }
+inline int dtype_bytes(int dt) { return (dt == CVVDP_U8 || dt == CVVDP_YUV8) ? 1 : (dt == CVVDP_U16 || dt == CVVDP_F16 || dt == CVVDP_YUV16) ? 2 : 4; }
 
 }  // namespace cvvdp

@@ -21,24 +21,85 @@
 
 namespace cvvdp {
 
+// What a thread keeps of one not-yet-converted pixel.  RGB / DKL sources: the three samples as floats.  Planar Y'CbCr
+// sources (video_source_yuv.py:147-223): the luma code and the four bilinear taps of each chroma plane as integers,
+// so that a prefetched frame is not touched (and its loads not waited for) before it is converted.
+template <int DT, int V> struct Raw { float v[3][V]; };
+struct RawYuv { uint32_t y, u[4], w[4]; };
+template <> struct Raw<CVVDP_YUV8, 1> : RawYuv {};
+template <> struct Raw<CVVDP_YUV16, 1> : RawYuv {};
+constexpr bool is_yuv(int dt) { return dt == CVVDP_YUV8 || dt == CVVDP_YUV16; }
+
+// Per-thread constants of the source addressing.  RGB / DKL: none.  Y'CbCr: the chroma taps of this pixel --
+// torch.nn.functional.interpolate(mode='bilinear', align_corners=False) as used at video_source_yuv.py:212-216:
+// source coordinate max((i + 0.5) / factor - 0.5, 0), neighbour clamped to the last sample.
+template <int DT> struct PixCtx { __device__ PixCtx(const FirArgs&, int, int, int) {} };
+struct YuvCtx {
+  int32_t pix, o[4];       // luma offset in the frame; chroma tap offsets inside a chroma plane (y0x0, y0x1, y1x0, y1x1)
+  float lx, ly;
+  __device__ YuvCtx(const FirArgs& a, int pix_, int y, int x) : pix(pix_) {
+    const YuvArgs& q = a.yuv;
+    const float sx = fmaxf(((float)x + 0.5f) * q.inv_fx - 0.5f, 0.0f), sy = fmaxf(((float)y + 0.5f) * q.inv_fy - 0.5f, 0.0f);
+    const int x0 = min((int)sx, q.Wc - 1), y0 = min((int)sy, q.Hc - 1);
+    const int x1 = min(x0 + 1, q.Wc - 1), y1 = min(y0 + 1, q.Hc - 1);
+    lx = sx - (float)x0; ly = sy - (float)y0;
+    o[0] = y0 * q.Wc + x0; o[1] = y0 * q.Wc + x1; o[2] = y1 * q.Wc + x0; o[3] = y1 * q.Wc + x1;
+  }
+};
+template <> struct PixCtx<CVVDP_YUV8> : YuvCtx { using YuvCtx::YuvCtx; };
+template <> struct PixCtx<CVVDP_YUV16> : YuvCtx { using YuvCtx::YuvCtx; };
+
 template <int DT, int V>
-__device__ __forceinline__ void load_pixels(const FirArgs& a, int side, int64_t off, float (&in)[3][V]) {
+__device__ __forceinline__ void load_pixels(const FirArgs& a, const PixCtx<DT>& cx, int side, int64_t off, Raw<DT, V>& in) {
   const void* src = a.src[side];
+  if constexpr (is_yuv(DT)) {
+    static_assert(V == 1, "planar Y'CbCr sources are read one pixel per thread");
+    // strides are (frame, W, 1): off = frame base + luma offset of this pixel
+    const int64_t fb = off - cx.pix;
+    auto ld = [&](int64_t i) -> uint32_t {
+      if constexpr (DT == CVVDP_YUV8) return reinterpret_cast<const uint8_t*>(src)[i];
+      else return reinterpret_cast<const uint16_t*>(src)[i];
+    };
+    in.y = ld(off);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) load_run<DT, V>(src, off + c * a.sc[side], in[c]);   // sc == 0 for 1-channel clips
+    for (int k = 0; k < 4; ++k) { in.u[k] = ld(fb + a.yuv.u_off + cx.o[k]); in.w[k] = ld(fb + a.yuv.v_off + cx.o[k]); }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) load_run<DT, V>(src, off + c * a.sc[side], in.v[c]);   // sc == 0 for 1-channel clips
+  }
 }
 
 template <int DT, int V>
-__device__ __forceinline__ void convert_pixels(const FirArgs& a, const float (&in)[3][V], float (&dkl)[3][V]) {
+__device__ __forceinline__ void convert_pixels(const FirArgs& a, const PixCtx<DT>& cx, const Raw<DT, V>& in, float (&dkl)[3][V]) {
+  if constexpr (is_yuv(DT)) {
+    const YuvArgs& q = a.yuv;
+    // limited-range fixed point -> float (video_source_yuv.py:197-210), bilinear chroma (:212-216), matrix + clip (:151-170)
+    const float Y = clipf(q.wy * (float)in.y - q.oy, 0.0f, 1.0f);
+    float ch[2];
 #pragma unroll
-  for (int i = 0; i < V; ++i) {
-    float v[3] = {in[0][i], in[1][i], in[2][i]}, o[3];
-    if constexpr (DT == CVVDP_F32_DKL) {
-      o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
-    } else {
-      pixel_to_dkl(a.dm, v, o);
+    for (int pl = 0; pl < 2; ++pl) {
+      float t[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] = clipf(q.wc * (float)(pl == 0 ? in.u[k] : in.w[k]) - q.oc, -0.5f, 0.5f);
+      const float top = t[0] * (1.0f - cx.lx) + t[1] * cx.lx, bot = t[2] * (1.0f - cx.lx) + t[3] * cx.lx;
+      ch[pl] = top * (1.0f - cx.ly) + bot * cx.ly;
     }
-    dkl[0][i] = o[0]; dkl[1][i] = o[1]; dkl[2][i] = o[2];
+    float v[3] = {clipf(Y + ch[1] * q.rv, 0.0f, 1.0f), clipf(Y + ch[0] * q.gu + ch[1] * q.gv, 0.0f, 1.0f),
+                  clipf(Y + ch[0] * q.bu, 0.0f, 1.0f)};
+    float o[3];
+    pixel_to_dkl(a.dm, v, o);
+    dkl[0][0] = o[0]; dkl[1][0] = o[1]; dkl[2][0] = o[2];
+  } else {
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      float v[3] = {in.v[0][i], in.v[1][i], in.v[2][i]}, o[3];
+      if constexpr (DT == CVVDP_F32_DKL) {
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+      } else {
+        pixel_to_dkl(a.dm, v, o);
+      }
+      dkl[0][i] = o[0]; dkl[1][i] = o[1]; dkl[2][i] = o[2];
+    }
   }
 }
 
@@ -61,6 +122,7 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
   if (pix >= a.P) return;
   const int b = blockIdx.y, side = blockIdx.z;
   const int y = pix / a.W, x = pix - y * a.W;
+  const PixCtx<DT> cx(a, pix, y, x);
   const int64_t off0 = b * a.sb[side] + (int64_t)y * a.sh[side] + (int64_t)x * a.sw[side];
   const int64_t sf = a.sf[side];
   float* hist = a.hist + side * a.h_side + b * a.h_b + pix;
@@ -82,9 +144,10 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
 #pragma unroll
           for (int i = 0; i < V; ++i) w[p][k][i] = w[p][k - 1][i];
       } else {
-        float in[3][V], d[3][V];
-        load_pixels<DT, V>(a, side, off0 + e * sf, in);
-        convert_pixels<DT, V>(a, in, d);
+        Raw<DT, V> in;
+        float d[3][V];
+        load_pixels<DT, V>(a, cx, side, off0 + e * sf, in);
+        convert_pixels<DT, V>(a, cx, in, d);
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -100,24 +163,20 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
   // software prefetch PF frames deep: with ~130 VGPRs only 3 waves/SIMD are resident, so the bytes in
   // flight per CU have to come from depth (3 waves x 4 SIMDs x PF frames x 3 loads x 512 B ~ 55 KB)
   constexpr int PF = CVVDP_FIR_PF;
-  float pf[PF][3][V];
+  Raw<DT, V> pf[PF];
 #pragma unroll
   for (int q = 0; q < PF; ++q)
-    if (q < a.n_frames) load_pixels<DT, V>(a, side, off0 + (int64_t)(a.raw_first + q) * sf, pf[q]);
+    if (q < a.n_frames) load_pixels<DT, V>(a, cx, side, off0 + (int64_t)(a.raw_first + q) * sf, pf[q]);
   for (int f0 = 0; f0 < a.n_frames; f0 += U) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int fi = f0 + u;
       if (fi < a.n_frames) {     // uniform
         float d[3][V];
-        convert_pixels<DT, V>(a, pf[0], d);
+        convert_pixels<DT, V>(a, cx, pf[0], d);
 #pragma unroll
-        for (int q = 0; q + 1 < PF; ++q)
-#pragma unroll
-          for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int i = 0; i < V; ++i) pf[q][p][i] = pf[q + 1][p][i];
-        if (fi + PF < a.n_frames) load_pixels<DT, V>(a, side, off0 + (int64_t)(a.raw_first + fi + PF) * sf, pf[PF - 1]);
+        for (int q = 0; q + 1 < PF; ++q) pf[q] = pf[q + 1];
+        if (fi + PF < a.n_frames) load_pixels<DT, V>(a, cx, side, off0 + (int64_t)(a.raw_first + fi + PF) * sf, pf[PF - 1]);
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -175,6 +234,7 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
   if (pix >= a.P) return;
   const int b = blockIdx.y, side = blockIdx.z;
   const int y = pix / a.W, x = pix - y * a.W;
+  const PixCtx<DT> cx(a, pix, y, x);
   const int64_t off0 = b * a.sb[side] + (int64_t)y * a.sh[side] + (int64_t)x * a.sw[side];
   const int64_t sf = a.sf[side];
   float* hist = a.hist + side * a.h_side + b * a.h_b + pix;
@@ -195,9 +255,9 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
     const int e = a.hist_src[k];
     float d[3][1];
     if (e >= 0) {
-      float in[3][1];
-      load_pixels<DT, 1>(a, side, off0 + e * sf, in);
-      convert_pixels<DT, 1>(a, in, d);
+      Raw<DT, 1> in;
+      load_pixels<DT, 1>(a, cx, side, off0 + e * sf, in);
+      convert_pixels<DT, 1>(a, cx, in, d);
     } else {
       for (int p = 0; p < 3; ++p) d[p][0] = hist[p * a.h_plane + (int64_t)(-1 - e) * a.h_slot];
     }
@@ -212,19 +272,19 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
   }
   float* out = a.out + (int64_t)b * a.P + pix;
   const int64_t o_item = (int64_t)a.batch * a.P;
-  constexpr int PF = 4;
-  float pf[PF][3][1];
+  constexpr int PF = is_yuv(DT) ? 2 : 4;   // nine integer samples per prefetched Y'CbCr pixel: keep the VGPR count at 5 waves/SIMD
+  Raw<DT, 1> pf[PF];
 #pragma unroll
   for (int q = 0; q < PF; ++q)
-    load_pixels<DT, 1>(a, side, off0 + (int64_t)(a.raw_first + min(q, a.n_frames - 1)) * sf, pf[q]);
+    load_pixels<DT, 1>(a, cx, side, off0 + (int64_t)(a.raw_first + min(q, a.n_frames - 1)) * sf, pf[q]);
   // One frame: convert prefetch slot Q, refill it with frame fi+PF, FIR, store.  The refill is unconditional (the
   // last PF frames re-read the last frame) and the frame loop is unrolled PF times with static prefetch slots, so
   // no register copies touch values still in flight and the compiler can wait with exact vmcnt(N) counts.
 #define CVVDP_FIR_FRAME(FI, Q)                                                                                   \
   {                                                                                                              \
     float d[3][1];                                                                                               \
-    convert_pixels<DT, 1>(a, pf[Q], d);                                                                          \
-    load_pixels<DT, 1>(a, side, off0 + (int64_t)(a.raw_first + min((FI) + PF, a.n_frames - 1)) * sf, pf[Q]);    \
+    convert_pixels<DT, 1>(a, cx, pf[Q], d);                                                                          \
+    load_pixels<DT, 1>(a, cx, side, off0 + (int64_t)(a.raw_first + min((FI) + PF, a.n_frames - 1)) * sf, pf[Q]);    \
     const int sw = __builtin_amdgcn_readfirstlane(sA == 0 ? M - 1 : sA - 1);   /* (A-1) mod M, in an SGPR */      \
     _Pragma("unroll") for (int p = 0; p < 3; ++p) { wlo[p][sw] = whi[p]; whi[p] = d[p][0]; }                     \
     const float* tb = a.taps_rot + (sA == 0 ? 0 : M - sA);                                                       \
@@ -268,6 +328,7 @@ __global__ __launch_bounds__(256) void k_fir_generic(FirArgs a) {
   const int item = blockIdx.y, side = blockIdx.z;
   const int fi = item / a.batch, b = item - fi * a.batch;
   const int y = pix / a.W, x = pix - y * a.W;
+  const PixCtx<DT> cx(a, pix, y, x);
   const int64_t off0 = b * a.sb[side] + (int64_t)y * a.sh[side] + (int64_t)x * a.sw[side];
   const float* hist = a.hist + side * a.h_side + b * a.h_b + pix;
   float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -276,9 +337,9 @@ __global__ __launch_bounds__(256) void k_fir_generic(FirArgs a) {
     float d[3][1];
     const int e = pos < a.fl - 1 ? (int)a.hist_src[pos] : a.raw_first + pos - (a.fl - 1);
     if (e >= 0) {
-      float in[3][1];
-      load_pixels<DT, 1>(a, side, off0 + e * a.sf[side], in);
-      convert_pixels<DT, 1>(a, in, d);
+      Raw<DT, 1> in;
+      load_pixels<DT, 1>(a, cx, side, off0 + e * a.sf[side], in);
+      convert_pixels<DT, 1>(a, cx, in, d);
     } else {
       for (int p = 0; p < 3; ++p) d[p][0] = hist[p * a.h_plane + (int64_t)(-1 - e) * a.h_slot];
     }
@@ -294,15 +355,16 @@ __global__ __launch_bounds__(256) void k_hist_generic(FirArgs a, float* tmp) {
   if (pix >= a.P) return;
   const int k = blockIdx.y % (a.fl - 1), b = blockIdx.y / (a.fl - 1), side = blockIdx.z;
   const int y = pix / a.W, x = pix - y * a.W;
+  const PixCtx<DT> cx(a, pix, y, x);
   const int64_t off0 = b * a.sb[side] + (int64_t)y * a.sh[side] + (int64_t)x * a.sw[side];
   const float* hist = a.hist + side * a.h_side + b * a.h_b + pix;
   const int pos = a.n_frames + k;                              // window position of new slot k
   const int e = pos < a.fl - 1 ? (int)a.hist_src[pos] : a.raw_first + pos - (a.fl - 1);
   float d[3][1];
   if (e >= 0) {
-    float in[3][1];
-    load_pixels<DT, 1>(a, side, off0 + e * a.sf[side], in);
-    convert_pixels<DT, 1>(a, in, d);
+    Raw<DT, 1> in;
+    load_pixels<DT, 1>(a, cx, side, off0 + e * a.sf[side], in);
+    convert_pixels<DT, 1>(a, cx, in, d);
   } else {
     for (int p = 0; p < 3; ++p) d[p][0] = hist[p * a.h_plane + (int64_t)(-1 - e) * a.h_slot];
   }
@@ -316,10 +378,14 @@ static void launch_fused(const FirArgs& a, hipStream_t s) {
   constexpr int VMAX = FL <= 17 ? 2 : 1;
   const int eb = dtype_bytes(a.dtype);
   static const int vcap = getenv("CVVDP_FIR_V") ? atoi(getenv("CVVDP_FIR_V")) : 1;   // tuning hook; 1 = scalar pixels + chunked window (fastest)
-  if (VMAX == 2 && vcap >= 2 && a.P % 2 == 0 && can_vectorise(2, a.W, a.sb, a.sc, a.sf, a.sh, a.sw, a.src, eb)) {
-    dim3 grid((a.P / 2 + 255) / 256, a.batch, 2);
-    hipLaunchKernelGGL((k_fir_fused<DT, FL, 2>), grid, dim3(256), 0, s, a);
-  } else {
+  if constexpr (VMAX == 2 && !is_yuv(DT)) {
+    if (vcap >= 2 && a.P % 2 == 0 && can_vectorise(2, a.W, a.sb, a.sc, a.sf, a.sh, a.sw, a.src, eb)) {
+      dim3 grid((a.P / 2 + 255) / 256, a.batch, 2);
+      hipLaunchKernelGGL((k_fir_fused<DT, FL, 2>), grid, dim3(256), 0, s, a);
+      return;
+    }
+  }
+  {
     dim3 grid((a.P + 255) / 256, a.batch, 2);
     static const bool rot = !(getenv("CVVDP_FIR_ROT") && atoi(getenv("CVVDP_FIR_ROT")) == 0);
     if constexpr (FL <= 17) {
@@ -352,6 +418,8 @@ void launch_fir(const FirArgs& a, float* hist_shadow, hipStream_t s) {
     case CVVDP_U16: fused = launch_dt<CVVDP_U16>(a, s); break;
     case CVVDP_F16: fused = launch_dt<CVVDP_F16>(a, s); break;
     case CVVDP_F32: fused = launch_dt<CVVDP_F32>(a, s); break;
+    case CVVDP_YUV8: fused = launch_dt<CVVDP_YUV8>(a, s); break;
+    case CVVDP_YUV16: fused = launch_dt<CVVDP_YUV16>(a, s); break;
     default: fused = launch_dt<CVVDP_F32_DKL>(a, s); break;
   }
   if (!fused && a.write_hist && a.fl > 1) {
@@ -361,6 +429,8 @@ void launch_fir(const FirArgs& a, float* hist_shadow, hipStream_t s) {
       case CVVDP_U16: hipLaunchKernelGGL(k_hist_generic<CVVDP_U16>, grid, dim3(256), 0, s, a, hist_shadow); break;
       case CVVDP_F16: hipLaunchKernelGGL(k_hist_generic<CVVDP_F16>, grid, dim3(256), 0, s, a, hist_shadow); break;
       case CVVDP_F32: hipLaunchKernelGGL(k_hist_generic<CVVDP_F32>, grid, dim3(256), 0, s, a, hist_shadow); break;
+      case CVVDP_YUV8: hipLaunchKernelGGL(k_hist_generic<CVVDP_YUV8>, grid, dim3(256), 0, s, a, hist_shadow); break;
+      case CVVDP_YUV16: hipLaunchKernelGGL(k_hist_generic<CVVDP_YUV16>, grid, dim3(256), 0, s, a, hist_shadow); break;
       default: hipLaunchKernelGGL(k_hist_generic<CVVDP_F32_DKL>, grid, dim3(256), 0, s, a, hist_shadow); break;
     }
     (void)hipMemcpyAsync(a.hist, hist_shadow, sizeof(float) * (size_t)2 * a.h_side, hipMemcpyDeviceToDevice, s);

@@ -175,6 +175,21 @@ class cvvdp(vq_metric):
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device available: colorvideovdp_amd has no CPU path")
         is_image = N_frames == 1
+        # a source that carries its own display photometry (video_source_dm, video_source.py:206-229) is measured
+        # with it; the metric's display geometry still sets the pixels per degree
+        src_dm = getattr(vid_source, "dm_photometry", None)
+        if src_dm is not None and src_dm is not self.display_photometry:
+            prev = self.display_photometry
+            self.display_photometry = src_dm
+            self._make_handle()
+            try:
+                return self._predict_video_source(vid_source, height, width, N_frames, is_image)
+            finally:
+                self.display_photometry = prev
+                self._make_handle()
+        return self._predict_video_source(vid_source, height, width, N_frames, is_image)
+
+    def _predict_video_source(self, vid_source, height, width, N_frames, is_image):
         first, count = 0, N_frames
         group = None
         if self._shard is not None and not is_image and torch.distributed.is_available() and torch.distributed.is_initialized():
@@ -261,8 +276,14 @@ class cvvdp(vq_metric):
         L = pyr_height + 1
         rho_band = freqs.copy()
         rho_band[L - 1] = 0.1  # cvvdp_metric.py:685-686
-        probe_t, probe_r, code = self._raw_block(vs, first, first + 1)
-        C = probe_t.shape[1]
+        is_yuv = hasattr(vs, "get_raw_yuv_block")      # planar Y'CbCr file source: unpacked by the temporal kernel
+        if is_yuv:
+            if is_image:
+                raise vq_exception("single-frame .yuv clips are not supported")
+            C = 3
+        else:
+            probe_t, probe_r, code = self._raw_block(vs, first, first + 1)
+            C = probe_t.shape[1]
         clip = _capi.Clip()
         clip.batch, clip.channels, clip.height, clip.width = B, C, height, width
         clip.is_video, clip.n_frames, clip.n_levels = int(not is_image), count, L
@@ -348,11 +369,17 @@ class cvvdp(vq_metric):
                     # later blocks: the DKL tail of the previous block is still in the workspace
                     lo, hi = ff, ff + n
                     hist = [-1 - k for k in range(fl - 1)]
-                t, r, code = self._raw_block(vs, lo, hi)
-                st, sr = self._strides(t, r)
                 hist_c = (ctypes.c_int32 * max(len(hist), 1))(*hist)
-                rc = lib.cvvdp_process_block(self._handle, t.data_ptr(), r.data_ptr(), code, st, sr, ff - lo, hist_c, n, ff - first, stream)
-                _capi.check(self._handle, rc, "cvvdp_process_block")
+                if is_yuv:
+                    t, r, fmt = vs.get_raw_yuv_block(lo, hi, self.device)
+                    rc = lib.cvvdp_process_block_yuv(self._handle, t.data_ptr(), r.data_ptr(), ctypes.byref(fmt), ff - lo, hist_c, n,
+                                                     ff - first, stream)
+                    _capi.check(self._handle, rc, "cvvdp_process_block_yuv")
+                else:
+                    t, r, code = self._raw_block(vs, lo, hi)
+                    st, sr = self._strides(t, r)
+                    rc = lib.cvvdp_process_block(self._handle, t.data_ptr(), r.data_ptr(), code, st, sr, ff - lo, hist_c, n, ff - first, stream)
+                    _capi.check(self._handle, rc, "cvvdp_process_block")
                 if self.do_heatmap:
                     fetch_heatmap(ff - first, n)
                 del t, r  # stream-ordered: safe to release to the caching allocator once the kernels are queued

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CVVDP_ABI_VERSION 3
+#define CVVDP_ABI_VERSION 4
 #define CVVDP_MAX_FILTER_LEN 65 /* 0.25 s at up to 256 fps, cvvdp_metric.py:1059 */
 #define CVVDP_MAX_LEVELS 16
 #define CVVDP_MAX_WINDOW 256    /* filter_len - 1 + frames per block */
@@ -43,7 +43,9 @@ enum {
 };
 
 /* input sample formats, video_source.py:320-346 */
-enum { CVVDP_U8 = 0, CVVDP_U16 = 1, CVVDP_F16 = 2, CVVDP_F32 = 3, CVVDP_F32_DKL = 4 /* already DKL-d65, fp32 */ };
+enum { CVVDP_U8 = 0, CVVDP_U16 = 1, CVVDP_F16 = 2, CVVDP_F32 = 3, CVVDP_F32_DKL = 4 /* already DKL-d65, fp32 */,
+       /* planar Y'CbCr frames, video_source_yuv.py:79-223; only through cvvdp_process_block_yuv */
+       CVVDP_YUV8 = 5, CVVDP_YUV16 = 6 };
 /* EOTFs, display_model.py:333-365 */
 enum { CVVDP_EOTF_SRGB = 0, CVVDP_EOTF_PQ = 1, CVVDP_EOTF_HLG = 2, CVVDP_EOTF_LINEAR = 3, CVVDP_EOTF_GAMMA = 4 };
 /* heat-map modes, cvvdp_metric.py:117 */
@@ -139,6 +141,25 @@ int cvvdp_put_image(cvvdp_handle* h, const void* dev_test, const void* dev_ref, 
 int cvvdp_process_block(cvvdp_handle* h, const void* dev_test, const void* dev_ref, int32_t dtype,
                         const int64_t strides_test[5], const int64_t strides_ref[5], int32_t raw_first,
                         const int32_t* hist_src, int32_t n_frames, int32_t q_frame_offset, void* stream);
+
+/* Planar Y'CbCr frames straight from a .yuv file.  Replaces YUVReader.get_frame_rgb_tensor /
+ * _fixed2float_upscale (video_source_yuv.py:147-170, 197-223) + video_source_dm.apply_dm_and_color_transform
+ * (video_source.py:217-229): limited-range fixed point -> float with clips, bilinear chroma up-sampling
+ * (torch interpolate, align_corners=False), BT.709 / BT.2020 Y'CbCr -> R'G'B' matrix, clip to [0,1]; then the
+ * display model, DKL and everything cvvdp_process_block does.  A frame is the Y plane followed by the U and the
+ * V plane (YUVReader.get_frame_yuv, :131-145); samples are uint8 (bit_depth 8) or uint16 (bit_depth 9..16).
+ * The clip must have been configured with channels = 3 and batch = 1. */
+typedef struct cvvdp_yuv_format {
+  int32_t chroma;         /* 420, 422 or 444 (video_source_yuv.py:98-112) */
+  int32_t bit_depth;      /* 8..16 */
+  int32_t matrix;         /* 709 or 2020 (video_source_yuv.py:151-160) */
+  int32_t reserved;
+  int64_t frame_stride_test, frame_stride_ref;   /* samples between consecutive frames of each buffer */
+} cvvdp_yuv_format;
+int cvvdp_process_block_yuv(cvvdp_handle* h, const void* dev_test, const void* dev_ref, const cvvdp_yuv_format* fmt,
+                            int32_t raw_first, const int32_t* hist_src, int32_t n_frames, int32_t q_frame_offset,
+                            void* stream);
+
 /* Image variant: pyramid, CSF, masking, pooling of the planes written by cvvdp_put_image. */
 int cvvdp_process_image(cvvdp_handle* h, void* stream);
 

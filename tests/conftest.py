@@ -16,8 +16,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _names(pattern):
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, pattern)))
+
+
 def golden_cases():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not p.endswith("setup.npz"))
+    """Array-input cases made by oracle/make_goldens.py."""
+    return [n for n in _names("*.npz") if n != "setup" and not n.startswith("yuv")]
+
+
+def yuv_cases():
+    """Planar Y'CbCr file cases made by oracle/make_goldens_yuv.py."""
+    return _names("yuv*.npz")
 
 
 def load_golden(name):

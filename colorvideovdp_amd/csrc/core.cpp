@@ -130,8 +130,19 @@ int run_pyramid_and_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, hip
   const int B = h->c.batch, items = n_frames * B, L = h->L, nch = h->nch;
   const float K[5] = {0.25f - 0.4f / 2.0f, 0.25f, 0.4f, 0.25f, 0.25f - 0.4f / 2.0f};  // lpyr_dec.py:179
   const int set = h->pipeline ? h->cur_set : 0;
+  static const bool fuse2 = !(getenv("CVVDP_REDUCE2") && atoi(getenv("CVVDP_REDUCE2")) == 0);   // tuning hook
   for (int l = 0; l + 1 < L; ++l) {
     ProfScope ps(h, CVVDP_PROF_REDUCE, s);
+    if (fuse2 && l + 2 < L && reduce2_supported(h->lv[l].H, h->lv[l].W)) {   // two levels per pass
+      Reduce2Args r{};
+      r.in = gbase(h, l, set); r.out1 = gbase(h, l + 1, set); r.out2 = gbase(h, l + 2, set);
+      r.H = h->lv[l].H; r.W = h->lv[l].W; r.H1 = h->lv[l + 1].H; r.W1 = h->lv[l + 1].W; r.H2 = h->lv[l + 2].H; r.W2 = h->lv[l + 2].W;
+      r.n_img = items; r.img_cap = h->items_cap; r.n_planes = 2 * nch;
+      for (int i = 0; i < 5; ++i) r.k[i] = K[i];
+      launch_reduce2(r, s);
+      ++l;
+      continue;
+    }
     ReduceArgs r{};
     r.in = gbase(h, l, set);
     r.out = gbase(h, l + 1, set);

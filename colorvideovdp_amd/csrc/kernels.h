@@ -83,6 +83,14 @@ struct ReduceArgs {
   float k[5];
 };
 void launch_reduce(const ReduceArgs& a, hipStream_t s);
+struct Reduce2Args {         // two levels per pass: l -> l+1 -> l+2
+  const float* in;           // level l
+  float *out1, *out2;        // levels l+1, l+2
+  int32_t H, W, H1, W1, H2, W2, n_img, img_cap, n_planes;
+  float k[5];
+};
+bool reduce2_supported(int H, int W);
+void launch_reduce2(const Reduce2Args& a, hipStream_t s);
 
 // ---------------------------------------------------------------- fused band kernel (K3..K7)
 struct BandArgs {

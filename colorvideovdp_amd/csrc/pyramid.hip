@@ -146,6 +146,128 @@ __global__ __launch_bounds__(256) void k_reduce_vec(ReduceArgs a) {
   }
 }
 
+// Two pyramid levels per pass: level l -> l+1 -> l+2 (W_l % 16 == 0).  The level l+1 rows a thread has just produced
+// in registers are reduced again on the spot, so level l+1 is written once and never read back by a reduce pass
+// (saves its 32*(1/4) B/pixel re-read: 4.25 GB per 64-frame 4K block).
+//   lane  <-> 4 adjacent level-(l+1) columns (as in k_reduce_vec) = 2 level-(l+2) columns; the two neighbouring
+//             columns each side come from the adjacent lanes by wave shuffles.  Lanes 0 and 63 of a wave only
+//             feed their neighbours: waves overlap by two lanes (3 % duplicated loads), so no LDS, no barriers;
+//   march <-> a thread walks down SEG2 level-(l+2) rows = 2*SEG2 level-(l+1) rows (+3 recomputed halo rows)
+//             = 4*SEG2 level-l rows, with the 5-row windows of both levels in registers.
+// Edge terms of both levels as in k_reduce_vec (lpyr_dec.py:195-209, including the row-parity column edge).
+constexpr int R2_LANES = 62;   // lanes of a wave that own level-(l+2) columns
+constexpr int R2_SEG = 64;     // level-(l+2) rows per thread
+
+__global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
+  const int img = blockIdx.z;
+  const int plane = img / a.n_img, it = img - plane * a.n_img;
+  const int64_t ib = (int64_t)plane * a.img_cap + it;
+  const float* in = a.in + ib * a.H * a.W;
+  float* out1 = a.out1 + ib * a.H1 * a.W1;
+  float* out2 = a.out2 + ib * a.H2 * a.W2;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int v = wave * R2_LANES + lane - 1;                 // quad index: level-(l+1) columns 4v .. 4v+3
+  const int nq = a.W1 >> 2;
+  if (wave * R2_LANES >= nq) return;                        // whole wave right of the image (wave-uniform)
+  const int c1 = 4 * v;
+  const bool in1 = v >= 0 && v < nq;
+  const bool own = in1 && lane >= 1 && lane <= R2_LANES;    // writes its level-(l+1) quad and 2 level-(l+2) columns
+  const bool first1 = v == 0, last1 = v == nq - 1;
+  const float k0 = a.k[0], k1 = a.k[1], k2 = a.k[2], k3 = a.k[3], k4 = a.k[4];
+  ReduceArgs ra;                                            // level l geometry for hreduce_row
+  ra.H = a.H; ra.W = a.W; ra.Wo = a.W1;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) ra.k[i] = a.k[i];
+
+  const int r2a = blockIdx.y * R2_SEG, r2b = min(r2a + R2_SEG, a.H2);
+  float w0[5][4];            // horizontally reduced level-l rows 2*y1-2 .. 2*y1+2 of the current level-(l+1) row y1
+  bool cold = true;
+  auto hrow0 = [&](int y, float (&h)[4]) {
+    if (y >= 0 && y < a.H && in1) hreduce_row(ra, in + (int64_t)y * a.W, c1, first1, last1, h);
+    else h[0] = h[1] = h[2] = h[3] = 0.0f;
+  };
+  // level-(l+1) row y1 -> its two horizontally reduced level-(l+2) samples (zero row outside the image)
+  auto l1row = [&](int y1, float (&hr)[2]) {
+    float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (y1 >= 0 && y1 < a.H1) {                             // block-uniform
+      if (cold) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) hrow0(2 * y1 - 2 + k, w0[k]);
+        cold = false;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { w0[0][j] = w0[2][j]; w0[1][j] = w0[3][j]; w0[2][j] = w0[4][j]; }
+      }
+      hrow0(2 * y1 + 1, w0[3]);
+      hrow0(2 * y1 + 2, w0[4]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = w0[0][j] * k0 + w0[1][j] * k1 + w0[2][j] * k2 + w0[3][j] * k3 + w0[4][j] * k4;
+      if (y1 == 0) {                                        // lpyr_dec.py:195
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += w0[2][j] * k1 + w0[3][j] * k0;
+      }
+      if (y1 == a.H1 - 1) {                                 // :196-199
+        if (a.H & 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += w0[2][j] * k3 + w0[1][j] * k4;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] += w0[3][j] * k4;
+        }
+      }
+      if (own && y1 >= 2 * r2a && y1 < 2 * r2b) *reinterpret_cast<float4*>(out1 + (int64_t)y1 * a.W1 + c1) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+      cold = true;
+    }
+    // second level, horizontal pass: level-(l+2) column 2v reads level-(l+1) columns 4v-2 .. 4v+2, column 2v+1 reads 4v .. 4v+4
+    const float l2 = __shfl_up(o[2], 1, 64), l3 = __shfl_up(o[3], 1, 64), rr0 = __shfl_down(o[0], 1, 64);
+    hr[0] = l2 * k0 + l3 * k1 + o[0] * k2 + o[1] * k3 + o[2] * k4;
+    hr[1] = o[0] * k0 + o[1] * k1 + o[2] * k2 + o[3] * k3 + rr0 * k4;
+    if (first1) hr[0] += o[0] * k1 + o[1] * k0;             // lpyr_dec.py:205 on level l+1
+    if (last1) {                                            // column W2-1 = 2v+1 (W1 % 8 == 0); sic: row parity (:206-209)
+      if (a.H1 & 1) hr[1] += o[3] * k3 + o[2] * k4;
+      else hr[1] += o[3] * k4;
+    }
+  };
+
+  float w2[5][2];            // horizontally reduced level-(l+1) rows 2*r2-2 .. 2*r2+2
+#pragma unroll
+  for (int k = 0; k < 3; ++k) l1row(2 * r2a - 2 + k, w2[k]);
+  for (int r2 = r2a; r2 < r2b; ++r2) {
+    if (r2 > r2a) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { w2[0][j] = w2[2][j]; w2[1][j] = w2[3][j]; w2[2][j] = w2[4][j]; }
+    }
+    l1row(2 * r2 + 1, w2[3]);
+    l1row(2 * r2 + 2, w2[4]);
+    float o2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) o2[j] = w2[0][j] * k0 + w2[1][j] * k1 + w2[2][j] * k2 + w2[3][j] * k3 + w2[4][j] * k4;
+    if (r2 == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) o2[j] += w2[2][j] * k1 + w2[3][j] * k0;
+    }
+    if (r2 == a.H2 - 1) {
+      if (a.H1 & 1) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) o2[j] += w2[2][j] * k3 + w2[1][j] * k4;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) o2[j] += w2[3][j] * k4;
+      }
+    }
+    if (own) *reinterpret_cast<float2*>(out2 + (int64_t)r2 * a.W2 + 2 * v) = make_float2(o2[0], o2[1]);
+  }
+}
+
+bool reduce2_supported(int H, int W) { return W % 16 == 0 && H >= 8; }
+
+void launch_reduce2(const Reduce2Args& a, hipStream_t s) {
+  const int nq = a.W1 / 4, waves = (nq + R2_LANES - 1) / R2_LANES;
+  dim3 grid((waves + 3) / 4, (a.H2 + R2_SEG - 1) / R2_SEG, a.n_planes * a.n_img);
+  hipLaunchKernelGGL(k_reduce2, grid, dim3(256), 0, s, a);
+}
+
 void launch_reduce(const ReduceArgs& a, hipStream_t s) {
   if (a.W % 8 == 0 && a.H >= 4) {
     dim3 grid((a.Wo / 4 + 255) / 256, (a.Ho + RSEG - 1) / RSEG, a.n_planes * a.n_img);

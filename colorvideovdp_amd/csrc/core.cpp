@@ -299,14 +299,16 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     lv.vec4 = lv.blur && (W % 8 == 0) && c.heatmap == CVVDP_HEATMAP_NONE;
     const int sw = lv.vec4 ? kBand4StripWidth : (lv.blur ? 256 - 2 * pad : 256);
     lv.n_strip = (W + sw - 1) / sw;
-    // Row segments: 256 rows amortise the 12 blur-halo rows of a segment to < 5 % on the big levels; small
-    // levels are latency-bound (one block marches ~2.5 us per row), so they are cut into shorter segments
-    // until ~1500 blocks exist for a nominal 16-frame block (down to 16 rows).
+    // Row segments.  Every segment recomputes 12 blur-halo rows, so segments should be long; a block marches ~2.6 us
+    // per row, so there must still be enough blocks to fill 256 CUs x 3.  Video: sized for the nominal 64-frame block
+    // (the split must not depend on the actual block size, or per-frame sums would round differently per block size):
+    // at most 384 rows, and no more segments than needed for ~768 blocks (4K: 360 rows at levels 0 and 1 = 3 % halo,
+    // 180 at level 2).  Images have one frame per launch: shorter segments, down to 16 rows.
     {
-      const int per_seg = lv.n_strip * 16 * c.batch;   // nominal 16 frames in flight: the split must not depend on the
-                                                        // block size, or per-frame sums would round differently per block size
-      const int want = (1536 + per_seg - 1) / per_seg;
-      const int lo = (H + 255) / 256, hi = std::max(lo, (H + 15) / 16);
+      const int nominal = c.is_video ? 64 : 16, target = c.is_video ? 768 : 1536, max_rows = c.is_video ? 384 : 256;
+      const int per_seg = lv.n_strip * nominal * c.batch;
+      const int want = (target + per_seg - 1) / per_seg;
+      const int lo = (H + max_rows - 1) / max_rows, hi = std::max(lo, (H + 15) / 16);
       lv.n_seg = std::min(std::max(want, lo), hi);
       lv.seg_h = (H + lv.n_seg - 1) / lv.n_seg;
       lv.n_seg = (H + lv.seg_h - 1) / lv.seg_h;

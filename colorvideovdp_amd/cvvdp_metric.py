@@ -332,12 +332,23 @@ class cvvdp(vq_metric):
         if self.do_heatmap:
             # The reference keeps the whole fp16 heat map on the CPU (cvvdp_metric.py:344).  Page-locked memory
             # + copies on a side stream keep the D2H traffic (6 B/pixel) off the compute stream.
+            # Page-locking gigabytes costs more than filling them (~60 ms per GB), so the buffer of the previous call is
+            # handed out again when nobody holds a tensor or array on it any more (callers get views: a live view shows
+            # up in the storage's use count).
             shape = [1, hm_ch, count, height, width]
-            try:
-                heatmap = torch.zeros(shape, dtype=torch.float16, device="cpu", pin_memory=True)
-                copy_stream = torch.cuda.Stream(self.device)
-            except RuntimeError:
-                heatmap = torch.zeros(shape, dtype=torch.float16, device="cpu")
+            base = getattr(self, "_hm_base", None)
+            if base is not None and base.numel() == int(np.prod(shape)) and torch._C._storage_Use_Count(base.untyped_storage()._cdata) <= 2:
+                heatmap = base.view(shape)
+                copy_stream = self._hm_stream
+            else:
+                self._hm_base = None
+                try:
+                    base = torch.empty(int(np.prod(shape)), dtype=torch.float16, device="cpu", pin_memory=True)   # every frame is written below
+                    copy_stream = torch.cuda.Stream(self.device)
+                    self._hm_base, self._hm_stream = base, copy_stream
+                    heatmap = base.view(shape)
+                except RuntimeError:
+                    heatmap = torch.empty(shape, dtype=torch.float16, device="cpu")
 
         def fetch_heatmap(ff, n):
             buf = torch.empty((hm_ch, n, height, width), dtype=torch.float16, device=self.device)

@@ -201,3 +201,27 @@ def test_full_size_properties():
     m2 = cv.cvvdp(display_name="standard_fhd", block_frames=3)
     _, s2 = m2.predict(test, ref, dim_order="BCFHW", frames_per_second=60)
     np.testing.assert_array_equal(s2["Q_per_ch"], q)
+
+
+def test_heatmap_host_buffer_is_reused_only_when_free():
+    """The page-locked heat-map buffer of the previous call is recycled, but never while a caller still holds it."""
+    import colorvideovdp_amd as cv
+    g = load_golden("vid_u8_135x240x18_60_fhd_raw")
+    met = _metric(g["meta"])
+    t, r = _inputs(g)
+    kw = dict(dim_order=g["meta"]["dim_order"], frames_per_second=g["meta"]["fps"])
+    _, s1 = met.predict(t, r, **kw)
+    h1 = s1["heatmap"]
+    keep = h1.clone()
+    _, s2 = met.predict(r, r, **kw)                       # h1 is alive: must not be overwritten
+    assert s2["heatmap"].data_ptr() != h1.data_ptr()
+    assert torch.equal(h1, keep)
+    p2 = s2["heatmap"].data_ptr()
+    view = s2["heatmap"][0, 0, 3]                          # a view alone keeps the buffer busy
+    del s2
+    _, s3 = met.predict(t, r, **kw)
+    assert s3["heatmap"].data_ptr() != p2 and torch.equal(s3["heatmap"], keep)
+    p3 = s3["heatmap"].data_ptr()
+    del s3, view
+    _, s4 = met.predict(t, r, **kw)                       # nothing refers to the last buffer any more: recycled
+    assert s4["heatmap"].data_ptr() == p3 and torch.equal(s4["heatmap"], keep)

@@ -484,6 +484,8 @@ static int process_block_impl(cvvdp_handle* h, const void* t, const void* r, int
     if (e >= 32767 || e < -(fl - 1)) return fail(h, CVVDP_E_ARG, "hist_src[%d] = %d out of range", k, e);
     f.hist_src[k] = (int16_t)e;
   }
+  f.halo_run = fl > 1 && raw_first >= fl - 1;
+  for (int k = 0; k < fl - 1 && f.halo_run; ++k) f.halo_run = hist_src[k] == raw_first - (fl - 1) + k;
   {
     ProfScope ps(h, CVVDP_PROF_FIR, s);
     launch_fir(f, h->ws + h->hist_shadow_off, s);

@@ -61,6 +61,7 @@ struct FirArgs {
   int32_t raw_first;       // raw frame index of the block's first scored frame
   int32_t abs_first;       // clip index of that frame (window rotation phase)
   int32_t write_hist;      // store the last fl-1 DKL frames for the next block
+  int32_t halo_run;        // hist_src is the run of raw frames raw_first-(fl-1) .. raw_first-1 (real halo frames of a shard)
   float* hist;             // [side][plane][slot][b][P]: DKL tail of the previous block
   int64_t h_side, h_plane, h_slot, h_b;
   float* out;              // level-0 planes [plane][item][P]

@@ -250,8 +250,13 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
   v16f wlo[3];
   float whi[3];
   int sA = ((a.abs_first % M) + M) % M;               // A mod M for the frame about to be processed
+  constexpr int PF = is_yuv(DT) ? 2 : 4;   // nine integer samples per prefetched Y'CbCr pixel: keep the VGPR count at 5 waves/SIMD
+  // A frame-range shard starts with M real halo frames that sit right before its first frame (hist_src = a run of raw
+  // frames): they are pushed through the same pipelined loop as the scored frames, minus the FIR and the stores,
+  // instead of one exposed memory round trip per entry.
+  const bool warm = a.halo_run && (M % PF == 0);
   // ---- prologue: window positions 0..M-1 of the first frame = frames A0-M .. A0-1
-  for (int k = 0; k < M; ++k) {
+  for (int k = 0; k < (warm ? 0 : M); ++k) {
     const int e = a.hist_src[k];
     float d[3][1];
     if (e >= 0) {
@@ -272,11 +277,26 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
   }
   float* out = a.out + (int64_t)b * a.P + pix;
   const int64_t o_item = (int64_t)a.batch * a.P;
-  constexpr int PF = is_yuv(DT) ? 2 : 4;   // nine integer samples per prefetched Y'CbCr pixel: keep the VGPR count at 5 waves/SIMD
   Raw<DT, 1> pf[PF];
+  const int f_start = warm ? -M : 0;
 #pragma unroll
   for (int q = 0; q < PF; ++q)
-    load_pixels<DT, 1>(a, cx, side, off0 + (int64_t)(a.raw_first + min(q, a.n_frames - 1)) * sf, pf[q]);
+    load_pixels<DT, 1>(a, cx, side, off0 + (int64_t)(a.raw_first + min(f_start + q, a.n_frames - 1)) * sf, pf[q]);
+  if (warm) {
+    whi[0] = whi[1] = whi[2] = 0.0f;                  // lands in the slot that frame A0-1 overwrites before it is read
+    for (int fw = -M; fw < 0; fw += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        float d[3][1];
+        convert_pixels<DT, 1>(a, cx, pf[u], d);
+        load_pixels<DT, 1>(a, cx, side, off0 + (int64_t)(a.raw_first + min(fw + u + PF, a.n_frames - 1)) * sf, pf[u]);
+        const int sw = __builtin_amdgcn_readfirstlane(sA == 0 ? M - 1 : sA - 1);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { wlo[p][sw] = whi[p]; whi[p] = d[p][0]; }
+        sA = (sA + 1 == M) ? 0 : sA + 1;
+      }
+    }
+  }
   // One frame: convert prefetch slot Q, refill it with frame fi+PF, FIR, store.  The refill is unconditional (the
   // last PF frames re-read the last frame) and the frame loop is unrolled PF times with static prefetch slots, so
   // no register copies touch values still in flight and the compiler can wait with exact vmcnt(N) counts.

@@ -76,27 +76,42 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
 // horizontal (the two passes act on different axes); only fp32 rounding order differs (~1e-7).
 constexpr int RSEG = 32;  // output rows per thread
 
-__device__ __forceinline__ void hreduce_row(const ReduceArgs& a, const float* row, int ox, bool first, bool last, float (&h)[4]) {
-  // input columns 2*ox-4 .. 2*ox+11 (three aligned float4 + one more), zero outside the image
+// Every call issues the same four 16-byte loads (no control flow around them), so a thread can keep several rows in
+// flight and wait with exact counts.  Rows and columns outside the image are the reference's zero padding: the
+// address is clamped into the image and the loaded values are multiplied by 0.  EDGE = the block touches the left or
+// right image border (block-uniform); interior blocks skip the column clamps and masks.
+template <bool EDGE>
+__device__ __forceinline__ void hreduce_row(const ReduceArgs& a, const float* img, int y, float live, int ox, bool first, bool last, float (&h)[4]) {
+  // input columns 2*ox-4 .. 2*ox+11 (three aligned float4 + one more)
   const int ix = 2 * ox - 4;
+  const float* row = img + (int64_t)min(max(y, 0), a.H - 1) * a.W;
+  const float my = (y >= 0 && y < a.H) ? live : 0.0f;
   float v[16];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int x = ix + 4 * q;
-    float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (x >= 0 && x < a.W) t = *reinterpret_cast<const float4*>(row + x);
+    float4 t;
+    if constexpr (EDGE) {
+      t = *reinterpret_cast<const float4*>(row + min(max(x, 0), a.W - 4));
+      const float mx = (x >= 0 && x < a.W) ? 1.0f : 0.0f;
+      t.x *= mx; t.y *= mx; t.z *= mx; t.w *= mx;
+    } else {
+      t = *reinterpret_cast<const float4*>(row + x);
+    }
     v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
   }
-  const float k0 = a.k[0], k1 = a.k[1], k2 = a.k[2], k3 = a.k[3], k4 = a.k[4];
+  const float k0 = a.k[0] * my, k1 = a.k[1] * my, k2 = a.k[2] * my, k3 = a.k[3] * my, k4 = a.k[4] * my;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {  // output column ox+j: taps at input 2(ox+j)-2 .. +2 = v[2j+2 .. 2j+6]
     h[j] = v[2 * j + 2] * k0 + v[2 * j + 3] * k1 + v[2 * j + 4] * k2 + v[2 * j + 5] * k3 + v[2 * j + 6] * k4;
   }
-  if (first) h[0] += v[4] * k1 + v[5] * k0;                       // lpyr_dec.py:205 (columns 0 and 1)
-  if (last) {                                                       // output column Wo-1 = ox+3, W even here
-    const int c1 = a.W - 1 - ix, c2 = a.W - 2 - ix;                 // always 11 and 10 for W % 8 == 0
-    if (a.H & 1) h[3] += v[c1] * k3 + v[c2] * k4;                   // sic: row parity (lpyr_dec.py:206-207)
-    else h[3] += v[c1] * k4;                                        // :209
+  if constexpr (EDGE) {
+    if (first) h[0] += v[4] * k1 + v[5] * k0;                     // lpyr_dec.py:205 (columns 0 and 1)
+    if (last) {                                                     // output column Wo-1 = ox+3, W even here
+      const int c1 = a.W - 1 - ix, c2 = a.W - 2 - ix;               // always 11 and 10 for W % 8 == 0
+      if (a.H & 1) h[3] += v[c1] * k3 + v[c2] * k4;                 // sic: row parity (lpyr_dec.py:206-207)
+      else h[3] += v[c1] * k4;                                      // :209
+    }
   }
 }
 
@@ -112,9 +127,10 @@ __global__ __launch_bounds__(256) void k_reduce_vec(ReduceArgs a) {
   const float k0 = a.k[0], k1 = a.k[1], k2 = a.k[2], k3 = a.k[3], k4 = a.k[4];
   // window of horizontally reduced input rows y-4 .. y ; rows outside the image are zero (+ edge terms)
   float w[5][4];
+  const bool edge = blockIdx.x == 0 || (blockIdx.x + 1) * 1024 >= a.Wo;     // block-uniform
   auto hrow = [&](int y, float (&h)[4]) {
-    if (y >= 0 && y < a.H) hreduce_row(a, in + (int64_t)y * a.W, ox, first, last, h);
-    else h[0] = h[1] = h[2] = h[3] = 0.0f;
+    if (edge) hreduce_row<true>(a, in, y, 1.0f, ox, first, last, h);
+    else hreduce_row<false>(a, in, y, 1.0f, ox, false, false, h);
   };
 #pragma unroll
   for (int k = 0; k < 3; ++k) hrow(2 * oy0 - 2 + k, w[k]);         // rows 2oy-2, 2oy-1, 2oy of the first output
@@ -182,9 +198,13 @@ __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
   const int r2a = blockIdx.y * R2_SEG, r2b = min(r2a + R2_SEG, a.H2);
   float w0[5][4];            // horizontally reduced level-l rows 2*y1-2 .. 2*y1+2 of the current level-(l+1) row y1
   bool cold = true;
+  // block-uniform: does this block hold the lanes left of column 0 or at / beyond the last quad?
+  const int wave0 = (blockIdx.x * 256) >> 6;
+  const bool edge = wave0 == 0 || (wave0 + 4) * R2_LANES + 1 >= nq;
+  const float live = in1 ? 1.0f : 0.0f;
   auto hrow0 = [&](int y, float (&h)[4]) {
-    if (y >= 0 && y < a.H && in1) hreduce_row(ra, in + (int64_t)y * a.W, c1, first1, last1, h);
-    else h[0] = h[1] = h[2] = h[3] = 0.0f;
+    if (edge) hreduce_row<true>(ra, in, y, live, c1, first1, last1, h);
+    else hreduce_row<false>(ra, in, y, 1.0f, c1, false, false, h);
   };
   // level-(l+1) row y1 -> its two horizontally reduced level-(l+2) samples (zero row outside the image)
   auto l1row = [&](int y1, float (&hr)[2]) {

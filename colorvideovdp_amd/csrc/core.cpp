@@ -459,7 +459,8 @@ static int process_block_impl(cvvdp_handle* h, const void* t, const void* r, int
   if (yuv) f.yuv = *yuv;
   fill_display(h, f.dm);
   f.W = c.width; f.P = (int)P0; f.batch = c.batch; f.n_frames = n_frames; f.fl = fl;
-  f.raw_first = raw_first; f.write_hist = 1;
+  f.raw_first = raw_first;
+  f.write_hist = q_frame_offset + n_frames < c.n_frames;   // the DKL tail is only read by the next block of this clip
   f.abs_first = c.first_frame + q_frame_offset;
   f.hist = h->ws + h->hist_off;
   f.h_b = P0; f.h_slot = (int64_t)c.batch * P0; f.h_plane = (int64_t)(fl - 1) * f.h_slot; f.h_side = 3 * f.h_plane;

@@ -25,6 +25,12 @@ timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 timeout 900 python bench.py --workload fhd64 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --workload 4k256 --cpu-frames 0 --steps 2 --warmup 1 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --dtype u8 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
+timeout 900 python bench.py --dtype yuv420p8 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
+timeout 900 python bench.py --dtype yuv420p10 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
+# 3b. heat-map path (configs[4] shape per GPU) and the shard-halo cost
+timeout 900 python tools/heatmap_bench.py 4k 32 > $OUT/${TAG}_heatmap_bench.txt 2>&1
+timeout 900 python tools/heatmap_bench.py 8k 24 >> $OUT/${TAG}_heatmap_bench.txt 2>&1
+timeout 600 python tools/shard_halo_bench.py > $OUT/${TAG}_shard_halo_bench.txt 2>&1
 # 4. GPU test log
 timeout 900 python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest_gpu.log 2>&1
 tail -3 $OUT/${TAG}_pytest_gpu.log; cat $OUT/${TAG}_bench.json

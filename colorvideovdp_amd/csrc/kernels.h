@@ -88,6 +88,7 @@ struct Reduce2Args {         // two levels per pass: l -> l+1 -> l+2
   const float* in;           // level l
   float *out1, *out2;        // levels l+1, l+2
   int32_t H, W, H1, W1, H2, W2, n_img, img_cap, n_planes;
+  int32_t seg2;              // level-(l+2) rows per thread (set by launch_reduce2)
   float k[5];
 };
 bool reduce2_supported(int H, int W);

@@ -9,6 +9,7 @@
 // staged in LDS with coalesced row loads, the vertical pass writes a 32 x 67 intermediate to LDS, the
 // horizontal pass reads it.  Every input pixel is fetched from HBM/L2 once per tile (+ the 3-pixel
 // apron).
+#include <algorithm>
 #include "kernels.h"
 
 namespace cvvdp {
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void k_reduce_vec(ReduceArgs a) {
 //             = 4*SEG2 level-l rows, with the 5-row windows of both levels in registers.
 // Edge terms of both levels as in k_reduce_vec (lpyr_dec.py:195-209, including the row-parity column edge).
 constexpr int R2_LANES = 62;   // lanes of a wave that own level-(l+2) columns
-constexpr int R2_SEG = 64;     // level-(l+2) rows per thread
+constexpr int R2_SEG = 64;     // most level-(l+2) rows per thread (launch_reduce2 balances the segments)
 
 __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
   const int img = blockIdx.z;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
 #pragma unroll
   for (int i = 0; i < 5; ++i) ra.k[i] = a.k[i];
 
-  const int r2a = blockIdx.y * R2_SEG, r2b = min(r2a + R2_SEG, a.H2);
+  const int r2a = blockIdx.y * a.seg2, r2b = min(r2a + a.seg2, a.H2);
   float w0[5][4];            // horizontally reduced level-l rows 2*y1-2 .. 2*y1+2 of the current level-(l+1) row y1
   bool cold = true;
   // block-uniform: does this block hold the lanes left of column 0 or at / beyond the last quad?
@@ -282,9 +283,16 @@ __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
 
 bool reduce2_supported(int H, int W) { return W % 16 == 0 && H >= 8; }
 
-void launch_reduce2(const Reduce2Args& a, hipStream_t s) {
-  const int nq = a.W1 / 4, waves = (nq + R2_LANES - 1) / R2_LANES;
-  dim3 grid((waves + 3) / 4, (a.H2 + R2_SEG - 1) / R2_SEG, a.n_planes * a.n_img);
+void launch_reduce2(const Reduce2Args& a0, hipStream_t s) {
+  Reduce2Args a = a0;
+  const int nq = a.W1 / 4, waves = (nq + R2_LANES - 1) / R2_LANES, bx = (waves + 3) / 4;
+  // equal row segments of at most R2_SEG rows (3 recomputed halo rows each), more of them when the launch would
+  // otherwise have fewer than ~4096 blocks (small frames), down to 16 rows
+  int n_seg = (a.H2 + R2_SEG - 1) / R2_SEG;
+  const int64_t per_seg = (int64_t)bx * a.n_planes * a.n_img;
+  n_seg = (int)std::max<int64_t>(n_seg, std::min<int64_t>((4096 + per_seg - 1) / per_seg, (a.H2 + 15) / 16));
+  a.seg2 = (a.H2 + n_seg - 1) / n_seg;
+  dim3 grid(bx, (a.H2 + a.seg2 - 1) / a.seg2, a.n_planes * a.n_img);
   hipLaunchKernelGGL(k_reduce2, grid, dim3(256), 0, s, a);
 }
 

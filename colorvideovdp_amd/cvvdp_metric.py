@@ -232,7 +232,9 @@ class cvvdp(vq_metric):
             per_frame = pix * batch * (2 * (2 * nch * 4 * 1.34)) + (pix * 16 if self.do_heatmap else 0)
             fixed = pix * batch * 24 * (fl - 1)
             nb = int((budget - fixed) // per_frame)
-            nb = min(nb, 64)
+            # heat maps leave the GPU over PCIe (2-6 B/pixel): 16-frame blocks let the copy of a block overlap the
+            # kernels of the next one (4K supra-threshold, 64 frames: 111 ms as one block, 81 ms in blocks of 16)
+            nb = min(nb, 16 if self.do_heatmap else 64)
         return max(1, min(nb, n_frames, _capi.MAX_WINDOW - fl + 1))
 
     def _raw_block(self, vs, a, b):
@@ -353,12 +355,16 @@ class cvvdp(vq_metric):
         def fetch_heatmap(ff, n):
             buf = torch.empty((hm_ch, n, height, width), dtype=torch.float16, device=self.device)
             _capi.check(self._handle, lib.cvvdp_get_heatmap(self._handle, n, buf.data_ptr(), stream), "cvvdp_get_heatmap")
+            # one copy per colour plane: heatmap[0, ch, ff:ff+n] is contiguous on the host, the [3, n, H, W] slice of a
+            # longer clip is not (a strided D2H copy falls off the DMA path: 6x slower end to end)
             if copy_stream is None:
-                heatmap[0, :, ff:ff + n] = buf.cpu()
+                for ch in range(hm_ch):
+                    heatmap[0, ch, ff:ff + n] = buf[ch].cpu()
             else:
                 copy_stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(copy_stream):
-                    heatmap[0, :, ff:ff + n].copy_(buf, non_blocking=True)
+                    for ch in range(hm_ch):
+                        heatmap[0, ch, ff:ff + n].copy_(buf[ch], non_blocking=True)
                 buf.record_stream(copy_stream)
 
         if is_image:

@@ -53,7 +53,7 @@ __device__ __forceinline__ int refl(int i, int n) {
   return i;
 }
 
-template <int NCH>
+template <int NCH, bool HEAT>
 __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   constexpr int NP = 2 * NCH;
   // s_ve is a ring of two rows (row parity): the luminance planes (0, 1; wave 0) run TWO rows ahead so that all
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   __shared__ __attribute__((aligned(16))) float s_lum[4][256];             // 1/L_T, 1/L_R, CSF-LUT fraction, LUT byte offset
   __shared__ __attribute__((aligned(16))) float s_m[NCH][256];
   __shared__ __attribute__((aligned(16))) float s_q[NCH][256];
-  __shared__ __attribute__((aligned(16))) float s_d[B4_R + 1][NCH][256];
+  __shared__ __attribute__((aligned(16))) float s_d[B4_R + 1][NCH][B4_SW];   // lane-private ring of |T'-R'|: interior columns only
+  __shared__ __attribute__((aligned(16))) float s_h[HEAT ? NCH : 1][HEAT ? 256 : 4];   // heat-map terms of the pooled row, per channel
   __shared__ float s_lut[NCH][CVVDP_CSF_NODES + 1];                         // [32] = [31]: lerp partner of the last node
 
   const int t = threadIdx.x;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     const f4 q0 = lds_read4(&s_q[0][4 * j]), q1 = lds_read4(&s_q[1][4 * j]), q2 = lds_read4(&s_q[2][4 * j]);
     f4 q3 = f4{{0.0f, 0.0f, 0.0f, 0.0f}};
     if constexpr (NCH == 4) q3 = lds_read4(&s_q[3][4 * j]);
-    const f4 d = lds_read4(&s_d[ds][c][4 * j]);
+    const f4 d = lds_read4(&s_d[ds][c][4 * j - B4_HALO]);
     float D[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -199,6 +200,26 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     }
     if (a.ddump) *reinterpret_cast<float4*>(a.ddump + (int64_t)c * a.items_cap * P + (int64_t)item * P + (int64_t)y * W + fc0) =
         make_float4(D[0], D[1], D[2], D[3]);
+    if constexpr (HEAT) {   // this channel's term of the per-pixel channel norm (cvvdp_metric.py:728-734)
+      float ht[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ht[i] = fast_pow(D[i] * a.hw[c] + kEps, a.beta_tch) - a.eps_btch;
+      lds_write4(&s_h[c][4 * j], ht);
+    }
+  };
+  // heat-map band of row y from the channel terms published by stage3c (needs a barrier in between): one column
+  // per thread, lp_norm over channels, stored /band_mul as lpyr_dec_2.set_lband does (lpyr_dec.py:308-314)
+  auto heat_row = [&](int y) {
+    if constexpr (HEAT) {
+      for (int col = t; col < 256; col += 64 * NCH) {
+        const int xs = x0 - B4_HALO + col;
+        if (col >= B4_HALO && col < 256 - B4_HALO && xs < W) {
+          float sum = s_h[0][col] + s_h[1][col] + s_h[2][col];
+          if constexpr (NCH == 4) sum += s_h[3][col];
+          a.dchr[(int64_t)item * P + (int64_t)y * W + xs] = (fast_pow(sum + kEps, 1.0f / a.beta_tch) - a.eps_inv_btch) / a.band_mul;
+        }
+      }
+    }
   };
 
   // ---- prologue: expand rows (luminance: two of them), g prefetch and luminance terms for the first row
@@ -254,7 +275,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
       }
       lds_write4(&s_m[c][4 * j], m);
       const int ds = ((r % (B4_R + 1)) + (B4_R + 1)) % (B4_R + 1);
-      lds_write4(&s_d[ds][c][4 * j], d);
+      if (interior) lds_write4(&s_d[ds][c][4 * j - B4_HALO], d);
       // reflect padding of the blur at the image's left/right edge: mirror columns 1..6 / W-7..W-2
       if (fc0 < 8) {                                  // strip 0, lanes holding columns 0..7
 #pragma unroll
@@ -277,6 +298,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     // issue the global loads right after the barrier: coarse rows are consumed at the end of this phase
     // (-> s_ve), the g rows a whole iteration later
     const bool more = r + 1 < ye + B4_R;
+    if (yprev >= ys) heat_row(yprev);                 // terms of row yprev were published in phase 1
     const int rs = min(refl(r + ahead, H), H - 1);
     stage1_load(rs);
     pT = nT; pR = nR;                                 // row r+1, requested a whole iteration ago
@@ -339,6 +361,10 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   }
   // ---- epilogue: pooling stage of the last centre row
   if (interior && (ye - 1) >= ys) stage3c(ye - 1);
+  if constexpr (HEAT) {
+    __syncthreads();
+    if ((ye - 1) >= ys) heat_row(ye - 1);
+  }
 
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -350,8 +376,13 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
 
 void launch_band4(const BandArgs& a, hipStream_t s) {
   dim3 grid(a.n_strip, a.n_seg, a.items);
-  if (a.nch == 4) hipLaunchKernelGGL((k_band4<4>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_band4<3>), grid, dim3(192), 0, s, a);
+  if (a.dchr) {
+    if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_band4<3, true>), grid, dim3(192), 0, s, a);
+  } else {
+    if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_band4<3, false>), grid, dim3(192), 0, s, a);
+  }
 }
 
 }  // namespace cvvdp

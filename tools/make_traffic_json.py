@@ -13,7 +13,7 @@ def level0_row(path, counter):
     best = None
     for line in open(path):
         f = line.split()
-        if "k_band4<4>" in line and counter in f:
+        if "k_band4<4" in line and counter in f:
             i = f.index(counter)
             wg, disp, per = int(f[i - 1]), int(f[i + 1]), float(f[i + 3])
             if best is None or wg > best[0]:

@@ -329,7 +329,41 @@ __global__ __launch_bounds__(256) void k_expand_add(ExpandAddArgs a) {
   f[pix] += v;
 }
 
+// W % 4 == 0: a thread updates 4 adjacent fine pixels (one 16-byte read-modify-write) from a 3x4 coarse patch.
+// Same expressions as k_expand_add: vertical first, then horizontal, neighbours clamped per fine pixel.
+__global__ __launch_bounds__(256) void k_expand_add4(ExpandAddArgs a) {
+  const int wq = a.W >> 2;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.H * wq) return;
+  const int img = blockIdx.y;
+  const float* c = a.coarse + (int64_t)img * a.Hc * a.Wc;
+  float* f = a.fine + (int64_t)img * a.H * a.W;
+  const int y = q / wq, x = (q - y * wq) << 2;
+  const int my = y >> 1, mx = x >> 1;
+  const int y0 = max(my - 1, 0), y2 = min(my + 1, a.Hc - 1);
+  const float e0 = a.kx[0], e1 = a.kx[1], o = a.kx[2];
+  float v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cx = min(max(mx - 1 + k, 0), a.Wc - 1);
+    if (y & 1) v[k] = c[(int64_t)my * a.Wc + cx] * o + c[(int64_t)y2 * a.Wc + cx] * o;
+    else v[k] = c[(int64_t)y0 * a.Wc + cx] * e0 + c[(int64_t)my * a.Wc + cx] * e1 + c[(int64_t)y2 * a.Wc + cx] * e0;
+  }
+  float4* p = reinterpret_cast<float4*>(f + (int64_t)y * a.W + x);
+  float4 t = *p;
+  t.x += v[0] * e0 + v[1] * e1 + v[2] * e0;
+  t.y += v[1] * o + v[2] * o;
+  t.z += v[1] * e0 + v[2] * e1 + v[3] * e0;
+  t.w += v[2] * o + v[3] * o;
+  *p = t;
+}
+
 void launch_expand_add(const ExpandAddArgs& a, hipStream_t s) {
+  if (a.W % 4 == 0 && a.Wc >= 2) {
+    dim3 grid((a.H * (a.W / 4) + 255) / 256, a.n_img);
+    hipLaunchKernelGGL(k_expand_add4, grid, dim3(256), 0, s, a);
+    return;
+  }
   dim3 grid((a.H * a.W + 255) / 256, a.n_img);
   hipLaunchKernelGGL(k_expand_add, grid, dim3(256), 0, s, a);
 }

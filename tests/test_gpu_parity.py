@@ -225,3 +225,32 @@ def test_heatmap_host_buffer_is_reused_only_when_free():
     del s3, view
     _, s4 = met.predict(t, r, **kw)                       # nothing refers to the last buffer any more: recycled
     assert s4["heatmap"].data_ptr() == p3 and torch.equal(s4["heatmap"], keep)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_shapes_against_oracle(seed):
+    """Seeded sweep over sizes that hit every kernel variant (widths that are / are not multiples of 4, 8 and 16, odd
+    heights, one- and two-level reduce passes, rotating / chunked / generic FIR), padding modes and displays."""
+    import colorvideovdp_amd as cv
+    from oracle import cvvdp_oracle as orc
+    rng = np.random.default_rng(1000 + seed)
+    H, W = [(33, 47), (48, 64), (100, 180), (127, 256), (72, 336), (135, 240), (64, 100), (90, 160)][seed]
+    F, fps = [(1, 0), (2, 24), (5, 30), (20, 60), (7, 120), (19, 50), (4, 100), (33, 60)][seed]
+    disp = ["standard_fhd", "standard_4k", "standard_hdr_pq", "standard_fhd", "standard_4k", "standard_hdr_hlg", "standard_fhd", "standard_4k"][seed]
+    pad = "symmetric" if seed % 3 == 1 else "replicate"
+    y, x = np.mgrid[0:H, 0:W]
+    ref = np.stack([np.stack([0.45 + 0.3 * np.sin(2 * np.pi * (2.3 * x / W + f / 17.0) + c) * np.cos(2 * np.pi * 1.7 * y / H) for c in range(3)])
+                    for f in range(F)], axis=1)[None]                                   # [1,3,F,H,W]
+    test = np.clip(ref + 0.04 * rng.standard_normal(ref.shape) * (x > W // 3), 0, 1)
+    if seed % 2:
+        test, ref = np.round(test * 255).astype(np.uint8), np.round(np.clip(ref, 0, 1) * 255).astype(np.uint8)
+    else:
+        test, ref = test.astype(np.float32), np.clip(ref, 0, 1).astype(np.float32)
+    try:
+        o = orc.Oracle(display_name=disp, temp_padding=pad)
+    except Exception:
+        pytest.skip(f"display {disp} not in the shipped display models")
+    ojod, ostats = o.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
+    jod, stats = cv.cvvdp(display_name=disp, temp_padding=pad).predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
+    assert abs(float(jod) - float(ojod)) <= JOD_TOL
+    np.testing.assert_allclose(stats["Q_per_ch"], ostats["Q_per_ch"], rtol=2e-4, atol=2e-6)

@@ -19,6 +19,15 @@ def main(path):
         nm = n if len(n) <= 92 else n[:89] + "..."
         print("%-92s %7d %12.3f %11.1f %11.1f %11.1f %6.2f %5s %5s %7s %s..%s" % (nm, c, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total, vg, sg, lds, g0, g1))
     print("# total GPU kernel time: %.3f ms" % (total / 1e6))
+    # the same kernel runs once per pyramid level: break the cvvdp kernels down by launch size (level 0 = most workgroups)
+    rows2 = cur.execute("select name, grid_x*grid_y*grid_z/(workgroup_x*workgroup_y*workgroup_z) as wg, count(*), avg(duration), min(duration), max(duration) "
+                        "from kernels where name like '%cvvdp::%' group by name, wg having avg(duration) > 100000 order by avg(duration) desc").fetchall()
+    if rows2:
+        print("\n# cvvdp kernels by launch size (launches averaging > 0.1 ms)")
+        print("%-72s %10s %7s %11s %11s %11s" % ("kernel", "workgroups", "calls", "avg_us", "min_us", "max_us"))
+        for n, wg, c, avg, mn, mx in rows2:
+            nm = n if len(n) <= 72 else n[:69] + "..."
+            print("%-72s %10d %7d %11.1f %11.1f %11.1f" % (nm, wg, c, avg / 1e3, mn / 1e3, mx / 1e3))
     try:
         pm = cur.execute("select p.name, k.grid_x*k.grid_y*k.grid_z/(k.workgroup_x*k.workgroup_y*k.workgroup_z) as wg, p.counter_name, "
                          "count(distinct p.dispatch_id), sum(p.counter_value) from pmc_events p join kernels k on p.dispatch_id = k.dispatch_id "

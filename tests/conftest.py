@@ -22,7 +22,7 @@ def _names(pattern):
 
 def golden_cases():
     """Array-input cases made by oracle/make_goldens.py."""
-    return [n for n in _names("*.npz") if n != "setup" and not n.startswith("yuv")]
+    return [n for n in _names("*.npz") if n != "setup" and not n.startswith("yuv") and not n.startswith("fullsize")]
 
 
 def yuv_cases():
@@ -40,3 +40,22 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def setup_vectors():
     return dict(np.load(os.path.join(GOLDEN, "setup.npz"), allow_pickle=False))
+
+
+def fullsize_cases():
+    """Reference outputs on prefixes of bench.py's synthetic clips (oracle/make_goldens_fullsize.py); inputs are regenerated."""
+    return _names("fullsize*.npz")
+
+
+def fullsize_inputs(g):
+    """The clip prefix a fullsize_* fixture was made from, regenerated on the CPU; None if this torch build's CPU
+    generator does not reproduce it (checksums differ)."""
+    import torch
+    import bench
+    F, H, W = int(g["frames"]), int(g["height"]), int(g["width"])
+    frames = [bench.synth_frame(f, H, W, "cpu") for f in range(F)]
+    t = torch.stack([a for a, _ in frames], dim=1)[None]
+    r = torch.stack([b for _, b in frames], dim=1)[None]
+    if int(t.to(torch.int64).sum()) != int(g["checksum_test"]) or int(r.to(torch.int64).sum()) != int(g["checksum_ref"]):
+        return None
+    return t.numpy(), r.numpy()

@@ -254,3 +254,18 @@ def test_random_shapes_against_oracle(seed):
     jod, stats = cv.cvvdp(display_name=disp, temp_padding=pad).predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
     assert abs(float(jod) - float(ojod)) <= JOD_TOL
     np.testing.assert_allclose(stats["Q_per_ch"], ostats["Q_per_ch"], rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", __import__("conftest").fullsize_cases())
+def test_fullsize_prefix_against_reference(name):
+    """BASELINE-size frames (4K, 1080p) against outputs of the real reference on a prefix of bench.py's clip."""
+    import colorvideovdp_amd as cv
+    from conftest import fullsize_inputs
+    g = load_golden(name)
+    inp = fullsize_inputs(g)
+    if inp is None:
+        pytest.skip("this torch build's CPU generator does not reproduce the fixture's synthetic frames")
+    jod, stats = cv.cvvdp(display_name=str(g["display"])).predict(inp[0], inp[1], dim_order="BCFHW", frames_per_second=float(g["fps"]))
+    assert abs(float(jod) - float(g["jod"])) <= JOD_TOL
+    np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(stats["rho_band"], g["rho_band"], rtol=1e-12)

@@ -101,3 +101,17 @@ def test_photometry_ramps(setup_vectors):
     np.testing.assert_allclose(d.to_dkl(ramp).numpy(), s["fwd_gamma22"], rtol=1e-6, atol=1e-6)
     d = orc.Display(photometry=dict(Y_peak=300, contrast=2000, source_colorspace="sRGB", E_ambient=10, exposure=0.7), geometry=dict(resolution=(1920, 1200), ppd=60))
     np.testing.assert_allclose(d.to_dkl(ramp).numpy(), s["fwd_srgb_exp07"], rtol=1e-6, atol=1e-6)
+
+
+def test_oracle_fullsize_prefix_against_reference():
+    """The oracle on 1080p frames of bench.py's synthetic clip against the real reference (the 4K case runs in the GPU suite)."""
+    import pytest
+    from conftest import fullsize_inputs, load_golden
+    from oracle import cvvdp_oracle as orc
+    g = load_golden("fullsize_fhd_4f")
+    inp = fullsize_inputs(g)
+    if inp is None:
+        pytest.skip("this torch build's CPU generator does not reproduce the fixture's synthetic frames")
+    jod, stats = orc.Oracle(str(g["display"])).predict(inp[0], inp[1], dim_order="BCFHW", frames_per_second=float(g["fps"]))
+    assert abs(float(jod) - float(g["jod"])) <= 1e-4
+    np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-5, atol=2e-7)

@@ -327,7 +327,9 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     if (!fir_has_register_window(c.filter_len)) { h->hist_shadow_off = off; off += hist; }  // generic-FL path double-buffers the tail
   }
   {
-    static const bool pipe_env = !(getenv("CVVDP_PIPELINE") && atoi(getenv("CVVDP_PIPELINE")) == 0);
+    // off by default: since the kernels were tuned, overlapping the band stage of block k with FIR + reduce of block
+    // k+1 no longer gains anything (4K x 256: 84-87 ms either way) and costs a second pyramid set of workspace
+    static const bool pipe_env = getenv("CVVDP_PIPELINE") && atoi(getenv("CVVDP_PIPELINE")) != 0;
     h->pipeline = pipe_env && c.is_video && c.heatmap == CVVDP_HEATMAP_NONE && !c.debug_dump && c.n_frames > c.block_frames;
     const size_t start = off;
     for (auto& lv : h->lv) { lv.g_off = off; off += align_up((size_t)2 * h->nch * h->items_cap * lv.P); }

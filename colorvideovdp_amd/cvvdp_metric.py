@@ -218,10 +218,9 @@ class cvvdp(vq_metric):
     # ------------------------------------------------------------------ block planning
     def _pick_block_frames(self, pix, batch, n_frames, fl, nch):
         """Frames per process_block call.  Results do not depend on it (tested).  Larger blocks amortise the
-        (fl-1)-frame DKL tail that is written/re-read between blocks.  Clips longer than one block are
-        software-pipelined by the core (FIR+reduce of block k+1 on the caller's stream overlap the band
-        kernels of block k on an internal stream: +14 % on a 256-frame 4K clip), which needs two pyramid
-        sets in the workspace (cf. estimate_block_N, cvvdp_metric.py:565-594, for the memory model)."""
+        (fl-1)-frame DKL tail that is written/re-read between blocks (cf. estimate_block_N,
+        cvvdp_metric.py:565-594, for the memory model; CVVDP_PIPELINE=1 software-pipelines the blocks on a
+        second stream and needs two pyramid sets, which no longer pays off)."""
         if self.block_frames is not None:
             nb = int(self.block_frames)
         else:
@@ -229,7 +228,7 @@ class cvvdp(vq_metric):
             budget = free * 0.55
             if self.gpu_mem is not None:
                 budget = min(budget, self.gpu_mem * 1e9)
-            per_frame = pix * batch * (2 * (2 * nch * 4 * 1.34)) + (pix * 16 if self.do_heatmap else 0)
+            per_frame = pix * batch * (2 * nch * 4 * 1.34) + (pix * 16 if self.do_heatmap else 0)
             fixed = pix * batch * 24 * (fl - 1)
             nb = int((budget - fixed) // per_frame)
             # heat maps leave the GPU over PCIe (2-6 B/pixel): 16-frame blocks let the copy of a block overlap the

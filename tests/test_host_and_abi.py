@@ -44,8 +44,8 @@ def test_abi_argument_validation_without_gpu():
     assert lib.cvvdp_configure(h, ctypes.byref(clip)) == 0
     need = lib.cvvdp_workspace_bytes(h)
     P0 = 1080 * 1920
-    # DKL tail (6 planes x 16 frames) + two pyramid sets (block pipeline) of 8 planes x 16 frames x 4/3
-    assert need > (6 * 16 + 2 * 8 * 16 * 1.33) * P0 * 4 and need < (6 * 16 + 2 * 8 * 16 * 1.35) * P0 * 4 + (1 << 22)
+    # DKL tail (6 planes x 16 frames) + one pyramid set of 8 planes x 16 frames x 4/3
+    assert need > (6 * 16 + 8 * 16 * 1.33) * P0 * 4 and need < (6 * 16 + 8 * 16 * 1.35) * P0 * 4 + (1 << 22)
     assert lib.cvvdp_process_block(h, None, None, 3, None, None, 0, None, 1, 0, None) == -2  # no workspace bound
     lib.cvvdp_destroy(h)
 

@@ -19,43 +19,35 @@ from .display_model import vvdp_display_photo_eotf, vvdp_display_photometry
 from .video_source import video_source
 
 
+_RES = re.compile(r"(\d+)x(\d+)p?(\d+)?")
+_FIELD_ALIASES = {   # file-name field -> (property, value), video_source_yuv.py:37-60
+    **{k: ("chroma_ss", k) for k in ("444", "420", "422")},
+    **{k: ("bit_depth", 10) for k in ("10", "10b", "10bit")},
+    **{k: ("bit_depth", 8) for k in ("8", "8b", "8bit")},
+    **{k: ("color_space", "709") for k in ("709", "bt709", "sdr")},
+    **{k: ("color_space", "2020") for k in ("2020", "ct2020", "pq2020", "hdr")},
+}
+
+
 def decode_video_props(fname):
-    """Header fields encoded in the file name, e.g. clip_1920x1080_10b_420_2020_60fps.yuv (video_source_yuv.py:8-62)."""
-    vprops = dict(width=1920, height=1080, fps=24, bit_depth=8, color_space="709", chroma_ss="420")
-    bname = os.path.splitext(os.path.basename(fname))[0]
-    res_match = re.compile(r"(\d+)x(\d+)p?(\d+)?")
-    for field in bname.split("_"):
-        if res_match.match(field):
-            nums = re.findall(r"\d+", field)
-            if len(nums) < 2 or len(nums) > 3:
+    """Header fields encoded in the file name, e.g. clip_1920x1080_10b_420_2020_60fps.yuv (video_source_yuv.py:8-62).
+    Unknown fields are ignored; missing ones keep the reference's defaults (1080p, 24 fps, 8 bit, 4:2:0, BT.709)."""
+    props = {"width": 1920, "height": 1080, "fps": 24, "bit_depth": 8, "color_space": "709", "chroma_ss": "420"}
+    stem = os.path.splitext(os.path.basename(fname))[0]
+    for field in stem.split("_"):
+        if _RES.match(field):
+            nums = [int(n) for n in re.findall(r"\d+", field)]
+            if not 2 <= len(nums) <= 3:
                 raise ValueError("Cannot decode the resolution")
-            vprops["width"] = int(nums[0])
-            vprops["height"] = int(nums[1])
+            props["width"], props["height"] = nums[0], nums[1]
             if len(nums) == 3:
-                vprops["fps"] = int(nums[2])
-            continue
-        if field.endswith("fps"):
-            vprops["fps"] = float(field[:-3])
-            continue
-        if field in ("444", "420", "422"):
-            vprops["chroma_ss"] = field
-            continue
-        if field in ("10", "10b", "10bit"):
-            vprops["bit_depth"] = 10
-            continue
-        if field in ("8", "8b", "8bit"):
-            vprops["bit_depth"] = 8
-            continue
-        if field in ("2020", "709"):
-            vprops["color_space"] = field
-            continue
-        if field in ("bt709", "sdr"):
-            vprops["color_space"] = "709"
-            continue
-        if field in ("ct2020", "pq2020", "hdr"):
-            vprops["color_space"] = "2020"
-            continue
-    return vprops
+                props["fps"] = nums[2]
+        elif field.endswith("fps"):
+            props["fps"] = float(field[:-3])
+        elif field in _FIELD_ALIASES:
+            key, value = _FIELD_ALIASES[field]
+            props[key] = value
+    return props
 
 
 def create_yuv_fname(basename, vprops):

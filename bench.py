@@ -97,6 +97,7 @@ class ResidentYuvClip:
         from colorvideovdp_amd import _capi
         self.n_total, self.lo, self.hi, self.H, self.W, self.fps = n_total, lo, hi, H, W, fps
         self.dm_photometry = None
+        self.device_resident = True               # no PCIe transfers: the metric may use full-size blocks
         self.frame = H * W + 2 * (H // 2) * (W // 2)
         tdt = torch.uint8 if bit_depth == 8 else torch.int16
         self.bufs = [torch.empty((hi - lo) * self.frame, dtype=tdt, device=device) for _ in range(2)]

@@ -216,7 +216,7 @@ class cvvdp(vq_metric):
         return (Q_jod.squeeze(), stats)
 
     # ------------------------------------------------------------------ block planning
-    def _pick_block_frames(self, pix, batch, n_frames, fl, nch):
+    def _pick_block_frames(self, pix, batch, n_frames, fl, nch, host_resident=False):
         """Frames per process_block call.  Results do not depend on it (tested).  Larger blocks amortise the
         (fl-1)-frame DKL tail that is written/re-read between blocks (cf. estimate_block_N,
         cvvdp_metric.py:565-594, for the memory model; CVVDP_PIPELINE=1 software-pipelines the blocks on a
@@ -234,6 +234,8 @@ class cvvdp(vq_metric):
             # heat maps leave the GPU over PCIe (2-6 B/pixel): 16-frame blocks let the copy of a block overlap the
             # kernels of the next one (4K supra-threshold, 64 frames: 111 ms as one block, 81 ms in blocks of 16)
             nb = min(nb, 16 if self.do_heatmap else 64)
+            if host_resident and n_frames > 24:
+                nb = min(nb, 16)   # the upload of block k+1 (side stream, worker thread) hides behind the kernels of block k
         return max(1, min(nb, n_frames, _capi.MAX_WINDOW - fl + 1))
 
     def _raw_block(self, vs, a, b):
@@ -242,19 +244,36 @@ class cvvdp(vq_metric):
             return vs.get_raw_block(a, b, self.device)
         if isinstance(vs, video_source_array):
             t, r, code = vs.raw_arrays()
-            t = t[:, :, a:b]
-            r = r[:, :, a:b]
-            if t.device != self.device:
-                t = t.to(self.device, non_blocking=True)
-            if r.device != self.device:
-                r = r.to(self.device, non_blocking=True)
-            return t, r, code
+            return self._upload_frames(t, a, b), self._upload_frames(r, a, b), code
         # generic video_source: frames arrive one by one, already in DKL (cvvdp_metric.py:503-504)
         ts = [vs.get_test_frame(f, device=self.device, colorspace="DKLd65") for f in range(a, b)]
         rs = [vs.get_reference_frame(f, device=self.device, colorspace="DKLd65") for f in range(a, b)]
         t = torch.cat(ts, dim=2).to(torch.float32).contiguous()
         r = torch.cat(rs, dim=2).to(torch.float32).contiguous()
         return t, r, _capi.F32_DKL
+
+    def _upload_frames(self, x, a, b):
+        """Frames [a,b) of a BCFHW tensor on the device.  Host tensors are copied plane by plane: x[b, c, a:b] is
+        contiguous, the [B,C,a:b] slice of a longer clip is not, and a strided host-to-device copy first gathers on
+        the CPU (several times slower than the link)."""
+        if x.device == self.device:
+            return x[:, :, a:b]
+        if x.device.type != "cpu" or (a == 0 and b == x.shape[2]) or not x.is_contiguous():
+            return x[:, :, a:b].to(self.device, non_blocking=True)
+        out = torch.empty((x.shape[0], x.shape[1], b - a) + tuple(x.shape[3:]), dtype=x.dtype, device=self.device)
+        for i in range(x.shape[0]):
+            for c in range(x.shape[1]):
+                out[i, c].copy_(x[i, c, a:b], non_blocking=True)
+        return out
+
+    @staticmethod
+    def _host_resident(vs):
+        """Does the clip have to cross PCIe block by block (host arrays, .yuv files)?"""
+        if hasattr(vs, "get_raw_yuv_block"):
+            return not getattr(vs, "device_resident", False)
+        if isinstance(vs, video_source_array):
+            return vs.raw_arrays()[0].device.type == "cpu"
+        return False
 
     @staticmethod
     def _strides(t, r):
@@ -288,7 +307,8 @@ class cvvdp(vq_metric):
         # The clip description (temporal taps, CSF rows per band, block size) depends only on the geometry: repeated
         # calls on clips of the same shape reuse it, so the first kernel is not held back by ~0.4 ms of host set-up.
         key = (height, width, first, count, B, C, is_image, None if is_image else float(vs.get_frames_per_second()), self.heatmap,
-               bool(self.debug_dump), self.block_frames, self.gpu_mem, float(self.pix_per_deg), id(self.parameters), id(self.csf_table))
+               bool(self.debug_dump), self.block_frames, self.gpu_mem, float(self.pix_per_deg), id(self.parameters), id(self.csf_table),
+               self._host_resident(vs))
         cached = getattr(self, "_clip_cache", None)
         if cached is not None and cached[0] == key:
             clip, fl, F = cached[1], cached[2], cached[3]
@@ -312,7 +332,7 @@ class cvvdp(vq_metric):
                 taps = np.zeros((4, _capi.MAX_FILTER_LEN), dtype=f32)
                 taps[:, :fl] = F
                 clip.taps[:] = taps.reshape(-1).tolist()
-                nb = self._pick_block_frames(height * width, B, count, fl, nch)
+                nb = self._pick_block_frames(height * width, B, count, fl, nch, self._host_resident(vs))
                 clip.filter_len, clip.block_frames = fl, nb
                 self.last_block_frames = nb
             rows = np.zeros((_capi.MAX_LEVELS, 4, _capi.CSF_NODES), dtype=f32)
@@ -383,6 +403,7 @@ class cvvdp(vq_metric):
 
             if self.temp_padding not in ("replicate", "symmetric"):
                 raise RuntimeError(f'Unknown padding method "{self.temp_padding}"')
+            blocks = []
             for ff in range(first, first + count, nb):
                 n = min(nb, first + count - ff)
                 if ff == first:
@@ -396,20 +417,60 @@ class cvvdp(vq_metric):
                     # later blocks: the DKL tail of the previous block is still in the workspace
                     lo, hi = ff, ff + n
                     hist = [-1 - k for k in range(fl - 1)]
-                hist_c = (ctypes.c_int32 * max(len(hist), 1))(*hist)
+                blocks.append((ff, n, lo, hi, hist))
+
+            def fetch(blk):
+                _, _, lo, hi, _ = blk
                 if is_yuv:
-                    t, r, fmt = vs.get_raw_yuv_block(lo, hi, self.device)
-                    rc = lib.cvvdp_process_block_yuv(self._handle, t.data_ptr(), r.data_ptr(), ctypes.byref(fmt), ff - lo, hist_c, n,
-                                                     ff - first, stream)
-                    _capi.check(self._handle, rc, "cvvdp_process_block_yuv")
-                else:
-                    t, r, code = self._raw_block(vs, lo, hi)
-                    st, sr = self._strides(t, r)
-                    rc = lib.cvvdp_process_block(self._handle, t.data_ptr(), r.data_ptr(), code, st, sr, ff - lo, hist_c, n, ff - first, stream)
-                    _capi.check(self._handle, rc, "cvvdp_process_block")
-                if self.do_heatmap:
-                    fetch_heatmap(ff - first, n)
-                del t, r  # stream-ordered: safe to release to the caching allocator once the kernels are queued
+                    return vs.get_raw_yuv_block(lo, hi, self.device)
+                return self._raw_block(vs, lo, hi)
+
+            # Clips that live on the host cross PCIe one block ahead: a worker thread uploads block k+1 on a side stream
+            # while this thread queues the kernels of block k (the copy blocks its thread, not the GPU).
+            prefetch = len(blocks) > 1 and self._host_resident(vs)
+            if prefetch:
+                import concurrent.futures
+                h2d = torch.cuda.Stream(self.device)
+                main_stream = torch.cuda.current_stream(self.device)
+
+                dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+
+                def fetch_async(blk):
+                    torch.cuda.set_device(dev_index)   # the current device is per thread
+                    with torch.cuda.stream(h2d):
+                        out = fetch(blk)
+                        ev = torch.cuda.Event()
+                        ev.record(h2d)
+                    return out, ev
+
+                pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+                pending = pool.submit(fetch_async, blocks[0])
+            try:
+                for i, blk in enumerate(blocks):
+                    ff, n, lo, hi, hist = blk
+                    if prefetch:
+                        (t, r, third), ev = pending.result()
+                        pending = pool.submit(fetch_async, blocks[i + 1]) if i + 1 < len(blocks) else None
+                        main_stream.wait_event(ev)
+                        t.record_stream(main_stream)
+                        r.record_stream(main_stream)
+                    else:
+                        t, r, third = fetch(blk)
+                    hist_c = (ctypes.c_int32 * max(len(hist), 1))(*hist)
+                    if is_yuv:
+                        rc = lib.cvvdp_process_block_yuv(self._handle, t.data_ptr(), r.data_ptr(), ctypes.byref(third), ff - lo, hist_c, n,
+                                                         ff - first, stream)
+                        _capi.check(self._handle, rc, "cvvdp_process_block_yuv")
+                    else:
+                        st, sr = self._strides(t, r)
+                        rc = lib.cvvdp_process_block(self._handle, t.data_ptr(), r.data_ptr(), third, st, sr, ff - lo, hist_c, n, ff - first, stream)
+                        _capi.check(self._handle, rc, "cvvdp_process_block")
+                    if self.do_heatmap:
+                        fetch_heatmap(ff - first, n)
+                    del t, r  # stream-ordered: safe to release to the caching allocator once the kernels are queued
+            finally:
+                if prefetch:
+                    pool.shutdown(wait=True)
         Q = torch.empty((B, nch, count, L), dtype=torch.float32, device=self.device)
         _capi.check(self._handle, lib.cvvdp_get_q_per_ch(self._handle, Q.data_ptr(), stream), "cvvdp_get_q_per_ch")
         if copy_stream is not None:

@@ -26,7 +26,12 @@ OUT = os.path.join(HERE, "..", "tests", "golden")
 
 
 def main():
-    for name, W, H, F, fps, disp in (("fullsize_4k_3f", 3840, 2160, 3, 60, "standard_4k"), ("fullsize_fhd_4f", 1920, 1080, 4, 60, "standard_fhd")):
+    cases = (("fullsize_4k_3f", 3840, 2160, 3, 60, "standard_4k"), ("fullsize_fhd_4f", 1920, 1080, 4, 60, "standard_fhd"),
+             ("fullsize_8k_pq_2f", 7680, 4320, 2, 60, "standard_hdr_pq"))
+    only = sys.argv[1:]
+    for name, W, H, F, fps, disp in cases:
+        if only and name not in only:
+            continue
         frames = [bench.synth_frame(f, H, W, "cpu") for f in range(F)]
         t = torch.stack([a for a, _ in frames], dim=1)[None]   # [1,3,F,H,W] uint8
         r = torch.stack([b for _, b in frames], dim=1)[None]

@@ -12,7 +12,7 @@ MAX_WINDOW = 256
 CSF_NODES = 32
 PROF_N = 6
 PROF_NAMES = ("photometry", "temporal_fir", "pyr_reduce", "band_level0", "band_rest", "heatmap")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 U8, U16, F16, F32, F32_DKL, YUV8, YUV16 = range(7)
 HEATMAP = {None: 0, "none": 0, "raw": 1, "threshold": 2, "supra-threshold": 3}
@@ -54,6 +54,7 @@ class Clip(C.Structure):
         ("block_frames", C.c_int32),
         ("heatmap", C.c_int32),
         ("debug_dump", C.c_int32),
+        ("raw_halo", C.c_int32), ("reserved", C.c_int32),
         ("taps", C.c_float * (4 * MAX_FILTER_LEN)),
         ("csf_rows", C.c_float * (MAX_LEVELS * 4 * CSF_NODES)),
     ]

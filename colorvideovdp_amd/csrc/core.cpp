@@ -462,7 +462,7 @@ static int process_block_impl(cvvdp_handle* h, const void* t, const void* r, int
   fill_display(h, f.dm);
   f.W = c.width; f.P = (int)P0; f.batch = c.batch; f.n_frames = n_frames; f.fl = fl;
   f.raw_first = raw_first;
-  f.write_hist = q_frame_offset + n_frames < c.n_frames;   // the DKL tail is only read by the next block of this clip
+  f.write_hist = !c.raw_halo && q_frame_offset + n_frames < c.n_frames;   // the DKL tail is only read by the next block of this clip
   f.abs_first = c.first_frame + q_frame_offset;
   f.hist = h->ws + h->hist_off;
   f.h_b = P0; f.h_slot = (int64_t)c.batch * P0; f.h_plane = (int64_t)(fl - 1) * f.h_slot; f.h_side = 3 * f.h_plane;
@@ -485,6 +485,7 @@ static int process_block_impl(cvvdp_handle* h, const void* t, const void* r, int
   for (int k = 0; k < fl - 1; ++k) {
     const int e = hist_src[k];
     if (e >= 32767 || e < -(fl - 1)) return fail(h, CVVDP_E_ARG, "hist_src[%d] = %d out of range", k, e);
+    if (e < 0 && c.raw_halo) return fail(h, CVVDP_E_ARG, "hist_src[%d] refers to the DKL tail, but the clip was configured with raw_halo", k);
     f.hist_src[k] = (int16_t)e;
   }
   f.halo_run = fl > 1 && raw_first >= fl - 1;

@@ -321,6 +321,9 @@ class cvvdp(vq_metric):
             clip.first_frame = first
             clip.heatmap = _capi.HEATMAP[self.heatmap]
             clip.debug_dump = int(self.debug_dump)
+            # device-resident clips: later blocks re-read their fl-1 predecessor frames (like a shard's halo) instead of
+            # a DKL tail written by the previous block: 3.2 GB less HBM traffic per 64-frame 4K block
+            clip.raw_halo = int(not is_image and not self._host_resident(vs) and (is_yuv or isinstance(vs, video_source_array) or hasattr(vs, "get_raw_block")))
             fl, F = 1, None
             if not is_image:
                 F = hs.temporal_filters(vs.get_frames_per_second(), self.parameters["beta_tf"], self.parameters["sigma_tf"])
@@ -406,9 +409,10 @@ class cvvdp(vq_metric):
             blocks = []
             for ff in range(first, first + count, nb):
                 n = min(nb, first + count - ff)
-                if ff == first:
-                    # first block of the clip / shard: the fl-1 window positions before frame ff are real
-                    # halo frames or temporal padding; all of them are raw frames of the block handed in
+                if ff == first or clip.raw_halo:
+                    # first block of the clip / shard, and every block of a device-resident clip: the fl-1 window
+                    # positions before frame ff are real predecessor / halo frames or temporal padding; all of them
+                    # are raw frames of the block handed in
                     hist_frames = [src_index(ff - (fl - 1) + k) for k in range(fl - 1)]
                     lo = min(hist_frames + [ff])
                     hi = max(hist_frames + [ff + n - 1]) + 1

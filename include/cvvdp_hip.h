@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CVVDP_ABI_VERSION 4
+#define CVVDP_ABI_VERSION 5
 #define CVVDP_MAX_FILTER_LEN 65 /* 0.25 s at up to 256 fps, cvvdp_metric.py:1059 */
 #define CVVDP_MAX_LEVELS 16
 #define CVVDP_MAX_WINDOW 256    /* filter_len - 1 + frames per block */
@@ -98,6 +98,9 @@ typedef struct cvvdp_clip {
   int32_t block_frames;         /* max frames per process_block call */
   int32_t heatmap;              /* CVVDP_HEATMAP_* */
   int32_t debug_dump;           /* 1: keep per-pixel D of every band in the workspace (tests) */
+  int32_t raw_halo;             /* 1: every block is handed its filter_len-1 predecessor frames as raw frames (hist_src >= 0),
+                                   so no DKL tail is kept between blocks; 0: later blocks read the tail (hist_src < 0) */
+  int32_t reserved;
   float taps[4 * CVVDP_MAX_FILTER_LEN];                             /* F[c][k], not flipped */
   float csf_rows[CVVDP_MAX_LEVELS * 4 * CVVDP_CSF_NODES];           /* [band][ch][node] log10 S */
 } cvvdp_clip;

@@ -269,3 +269,22 @@ def test_fullsize_prefix_against_reference(name):
     assert abs(float(jod) - float(g["jod"])) <= JOD_TOL
     np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(stats["rho_band"], g["rho_band"], rtol=1e-12)
+
+
+def test_block_size_invariance_device_resident():
+    """Device-resident clips take the raw-halo route between blocks (no DKL tail): still bit-exact for any block size,
+    for both padding modes (blocks shorter than the filter re-read padded frames)."""
+    import colorvideovdp_amd as cv
+    for case in ("vid_u8_135x240x18_60_fhd_raw", "vid_u16_67x121x20_30_4k_sym"):
+        g = load_golden(case)
+        meta = dict(g["meta"]); meta["heatmap"] = None
+        t, r = _inputs(g)
+        t = torch.as_tensor(t.view(np.int16) if isinstance(t, np.ndarray) and t.dtype == np.uint16 else t).cuda()
+        r = torch.as_tensor(r.view(np.int16) if isinstance(r, np.ndarray) and r.dtype == np.uint16 else r).cuda()
+        qs = []
+        for nb in (None, 7, 3, 1):
+            _, st = _metric(meta, block_frames=nb).predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+            qs.append(st["Q_per_ch"])
+        np.testing.assert_allclose(qs[0], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
+        for q in qs[1:]:
+            np.testing.assert_array_equal(qs[0], q)

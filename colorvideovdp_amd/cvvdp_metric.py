@@ -33,6 +33,14 @@ from .vq_metric import register_metric, vq_exception, vq_metric
 f32 = np.float32
 
 
+def _storage_is_unshared(t):
+    """True if no tensor / array other than `t` itself refers to t's storage (private torch API; False if unavailable)."""
+    try:
+        return torch._C._storage_Use_Count(t.untyped_storage()._cdata) <= 2   # t + the temporary storage object
+    except Exception:
+        return False
+
+
 class cvvdp(vq_metric):
     def __init__(self, display_name="standard_4k", display_photometry=None, display_geometry=None, config_paths=[],
                  heatmap=None, quiet=False, device=None, temp_padding="replicate", use_checkpoints=False, dump_channels=None,
@@ -361,7 +369,7 @@ class cvvdp(vq_metric):
             # up in the storage's use count).
             shape = [1, hm_ch, count, height, width]
             base = getattr(self, "_hm_base", None)
-            if base is not None and base.numel() == int(np.prod(shape)) and torch._C._storage_Use_Count(base.untyped_storage()._cdata) <= 2:
+            if base is not None and base.numel() == int(np.prod(shape)) and _storage_is_unshared(base):
                 heatmap = base.view(shape)
                 copy_stream = self._hm_stream
             else:

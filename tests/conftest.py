@@ -22,7 +22,7 @@ def _names(pattern):
 
 def golden_cases():
     """Array-input cases made by oracle/make_goldens.py."""
-    return [n for n in _names("*.npz") if n != "setup" and not n.startswith("yuv") and not n.startswith("fullsize")]
+    return [n for n in _names("*.npz") if n != "setup" and not n.startswith(("yuv", "fullsize", "kat_"))]
 
 
 def yuv_cases():
@@ -59,3 +59,15 @@ def fullsize_inputs(g):
     if int(t.to(torch.int64).sum()) != int(g["checksum_test"]) or int(r.to(torch.int64).sum()) != int(g["checksum_ref"]):
         return None
     return t.numpy(), r.numpy()
+
+
+def kat_wavy_facade():
+    """The reference's documented known-answer case (examples/ex_simple_image.py:14-17): fixture + the test image made
+    with the example's own recipe (scipy gaussian_filter, sigma 2, mode 'nearest', truncate 2.0; ex_utils.py:27-41)."""
+    from scipy.ndimage import gaussian_filter
+    g = load_golden("kat_wavy_facade")
+    ref = g["ref"]
+    test = np.zeros_like(ref)
+    for c in range(3):
+        test[..., c] = gaussian_filter(ref[..., c], 2, mode="nearest", truncate=2.0)
+    return g, test, ref

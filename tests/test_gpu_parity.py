@@ -288,3 +288,18 @@ def test_block_size_invariance_device_resident():
         np.testing.assert_allclose(qs[0], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
         for q in qs[1:]:
             np.testing.assert_array_equal(qs[0], q)
+
+
+def test_documented_known_answer():
+    """The reference's own KAT (examples/ex_simple_image.py: 'Blur - Quality: 8.514 JOD'), heat map on as in the example."""
+    import colorvideovdp_amd as cv
+    from conftest import kat_wavy_facade
+    g, test, ref = kat_wavy_facade()
+    jod, stats = cv.cvvdp(display_name="standard_4k", heatmap="threshold").predict(test, ref, dim_order="HWC")
+    assert abs(float(jod) - 8.514) < 1.5e-3                      # documented, 3 decimals
+    assert abs(float(jod) - float(g["jod"])) <= JOD_TOL          # the real reference on the same samples
+    np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
+    hm = stats["heatmap"]
+    assert tuple(hm.shape) == (1, 3, 1, 683, 1024) and hm.dtype == torch.float16
+    d = np.abs(hm[0, :, 0, ::8, ::8].numpy().astype(np.float32) - g["heatmap_ds"].astype(np.float32))
+    assert (d > 2e-3).mean() < 1e-3 and d.max() <= 2e-2

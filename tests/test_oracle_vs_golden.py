@@ -115,3 +115,13 @@ def test_oracle_fullsize_prefix_against_reference():
     jod, stats = orc.Oracle(str(g["display"])).predict(inp[0], inp[1], dim_order="BCFHW", frames_per_second=float(g["fps"]))
     assert abs(float(jod) - float(g["jod"])) <= 1e-4
     np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-5, atol=2e-7)
+
+
+def test_oracle_reproduces_the_documented_known_answer():
+    """examples/ex_simple_image.py:14-17 documents 'Blur - Quality: 8.514 JOD' for wavy_facade.png (16-bit) on standard_4k."""
+    from conftest import kat_wavy_facade
+    g, test, ref = kat_wavy_facade()
+    jod, stats = orc.Oracle("standard_4k").predict(test, ref, dim_order="HWC")
+    assert round(float(jod), 3) == round(float(g["documented_jod"]), 3) == 8.514
+    assert abs(float(jod) - float(g["jod"])) <= 2e-5           # the real reference on the same samples: 8.51376
+    np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-5, atol=2e-7)

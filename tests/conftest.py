@@ -71,3 +71,20 @@ def kat_wavy_facade():
     for c in range(3):
         test[..., c] = gaussian_filter(ref[..., c], 2, mode="nearest", truncate=2.0)
     return g, test, ref
+
+
+def kat_nancy_church():
+    """The reference's documented HDR known-answer case (examples/ex_hdr_images.py:13-45): fixture (Radiance RGBE bytes),
+    reference / test images in cd/m^2 made with the example's recipe, and the display photometry arguments."""
+    from scipy.ndimage import gaussian_filter
+    g = load_golden("kat_nancy_church")
+    rgbe = g["rgbe"]
+    e = rgbe[..., 3].astype(np.int32)
+    scale = np.where(e > 0, np.ldexp(np.float32(1.0), e - 136), np.float32(0.0)).astype(np.float32)   # RGBE: mantissa * 2^(e-136)
+    img = rgbe[..., :3].astype(np.float32) * scale[..., None]
+    ref = (img / img.max() * 4000 * 4).astype(np.float32)                                              # ex_hdr_images.py:29
+    test = np.zeros_like(ref)
+    for c in range(3):
+        test[..., c] = gaussian_filter(ref[..., c], 2, mode="nearest", truncate=2.0)
+    photo = dict(Y_peak=4000, contrast=1000000, source_colorspace="BT.709", EOTF="linear", E_ambient=100)
+    return g, test, ref, photo

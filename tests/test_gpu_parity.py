@@ -303,3 +303,17 @@ def test_documented_known_answer():
     assert tuple(hm.shape) == (1, 3, 1, 683, 1024) and hm.dtype == torch.float16
     d = np.abs(hm[0, :, 0, ::8, ::8].numpy().astype(np.float32) - g["heatmap_ds"].astype(np.float32))
     assert (d > 2e-3).mean() < 1e-3 and d.max() <= 2e-2
+
+
+def test_documented_hdr_known_answer():
+    """The reference's HDR KAT (examples/ex_hdr_images.py: 'Blur - Quality: 8.696 JOD'): float32 cd/m^2 input, custom
+    linear-EOTF photometry on a named display geometry."""
+    import colorvideovdp_amd as cv
+    from conftest import kat_nancy_church
+    g, test, ref, photo = kat_nancy_church()
+    disp = cv.vvdp_display_photo_eotf(photo["Y_peak"], contrast=photo["contrast"], source_colorspace=photo["source_colorspace"],
+                                      EOTF=photo["EOTF"], E_ambient=photo["E_ambient"])
+    jod, stats = cv.cvvdp(display_name="standard_hdr_linear", display_photometry=disp, heatmap="threshold").predict(test, ref, dim_order="HWC")
+    assert abs(float(jod) - 8.696) < 1.5e-3
+    assert abs(float(jod) - float(g["jod"])) <= JOD_TOL
+    np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)

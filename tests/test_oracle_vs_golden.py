@@ -125,3 +125,13 @@ def test_oracle_reproduces_the_documented_known_answer():
     assert round(float(jod), 3) == round(float(g["documented_jod"]), 3) == 8.514
     assert abs(float(jod) - float(g["jod"])) <= 2e-5           # the real reference on the same samples: 8.51376
     np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-5, atol=2e-7)
+
+
+def test_oracle_reproduces_the_documented_hdr_known_answer():
+    """examples/ex_hdr_images.py:13-17 documents 'Blur - Quality: 8.696 JOD' for nancy_church.hdr on a linear-EOTF 4000 cd/m^2 display."""
+    from conftest import kat_nancy_church
+    g, test, ref, photo = kat_nancy_church()
+    jod, stats = orc.Oracle(display_name="standard_hdr_linear", photometry=photo).predict(test, ref, dim_order="HWC")
+    assert round(float(jod), 3) == round(float(g["documented_jod"]), 3) == 8.696
+    assert abs(float(jod) - float(g["jod"])) <= 2e-5
+    np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-5, atol=2e-7)

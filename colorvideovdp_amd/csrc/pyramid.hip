@@ -77,6 +77,14 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
 // horizontal (the two passes act on different axes); only fp32 rounding order differs (~1e-7).
 constexpr int RSEG = 32;  // output rows per thread
 
+// 5-tap dot product with a FIXED operation order.  The marching kernels evaluate the same taps from several inlined
+// copies of their row code (prologue / steady state); left to the compiler, each copy may contract a*b + c*d + ...
+// into FMAs differently, and a row's last bit would then depend on where its segment starts -- i.e. on the block size.
+__device__ __forceinline__ float dot5(float a0, float a1, float a2, float a3, float a4, float k0, float k1, float k2, float k3, float k4) {
+  return __builtin_fmaf(a4, k4, __builtin_fmaf(a3, k3, __builtin_fmaf(a2, k2, __builtin_fmaf(a1, k1, a0 * k0))));
+}
+__device__ __forceinline__ float dot2(float a0, float a1, float k0, float k1) { return __builtin_fmaf(a1, k1, a0 * k0); }
+
 // Every call issues the same four 16-byte loads (no control flow around them), so a thread can keep several rows in
 // flight and wait with exact counts.  Rows and columns outside the image are the reference's zero padding: the
 // address is clamped into the image and the loaded values are multiplied by 0.  EDGE = the block touches the left or
@@ -104,14 +112,14 @@ __device__ __forceinline__ void hreduce_row(const ReduceArgs& a, const float* im
   const float k0 = a.k[0] * my, k1 = a.k[1] * my, k2 = a.k[2] * my, k3 = a.k[3] * my, k4 = a.k[4] * my;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {  // output column ox+j: taps at input 2(ox+j)-2 .. +2 = v[2j+2 .. 2j+6]
-    h[j] = v[2 * j + 2] * k0 + v[2 * j + 3] * k1 + v[2 * j + 4] * k2 + v[2 * j + 5] * k3 + v[2 * j + 6] * k4;
+    h[j] = dot5(v[2 * j + 2], v[2 * j + 3], v[2 * j + 4], v[2 * j + 5], v[2 * j + 6], k0, k1, k2, k3, k4);
   }
   if constexpr (EDGE) {
-    if (first) h[0] += v[4] * k1 + v[5] * k0;                     // lpyr_dec.py:205 (columns 0 and 1)
+    if (first) h[0] += dot2(v[4], v[5], k1, k0);                  // lpyr_dec.py:205 (columns 0 and 1)
     if (last) {                                                     // output column Wo-1 = ox+3, W even here
       const int c1 = a.W - 1 - ix, c2 = a.W - 2 - ix;               // always 11 and 10 for W % 8 == 0
-      if (a.H & 1) h[3] += v[c1] * k3 + v[c2] * k4;                 // sic: row parity (lpyr_dec.py:206-207)
-      else h[3] += v[c1] * k4;                                      // :209
+      if (a.H & 1) h[3] += dot2(v[c1], v[c2], k3, k4);              // sic: row parity (lpyr_dec.py:206-207)
+      else h[3] = __builtin_fmaf(v[c1], k4, h[3]);                  // :209
     }
   }
 }
@@ -145,18 +153,18 @@ __global__ __launch_bounds__(256) void k_reduce_vec(ReduceArgs a) {
     hrow(2 * oy + 2, w[4]);
     float o[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = w[0][j] * k0 + w[1][j] * k1 + w[2][j] * k2 + w[3][j] * k3 + w[4][j] * k4;
+    for (int j = 0; j < 4; ++j) o[j] = dot5(w[0][j], w[1][j], w[2][j], w[3][j], w[4][j], k0, k1, k2, k3, k4);
     if (oy == 0) {                                                   // lpyr_dec.py:195: rows 0 and 1 = w[2], w[3]
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] += w[2][j] * k1 + w[3][j] * k0;
+      for (int j = 0; j < 4; ++j) o[j] += dot2(w[2][j], w[3][j], k1, k0);
     }
     if (oy == a.Ho - 1) {                                            // :196-199
       if (a.H & 1) {                                                 // centre row H-1 = w[2]; row H-2 = w[1]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] += w[2][j] * k3 + w[1][j] * k4;
+        for (int j = 0; j < 4; ++j) o[j] += dot2(w[2][j], w[1][j], k3, k4);
       } else {                                                       // centre row H-2 = w[2]; row H-1 = w[3]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] += w[3][j] * k4;
+        for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaf(w[3][j], k4, o[j]);
       }
     }
     *reinterpret_cast<float4*>(out + (int64_t)oy * a.Wo + ox) = make_float4(o[0], o[1], o[2], o[3]);
@@ -222,18 +230,18 @@ __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
       hrow0(2 * y1 + 1, w0[3]);
       hrow0(2 * y1 + 2, w0[4]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = w0[0][j] * k0 + w0[1][j] * k1 + w0[2][j] * k2 + w0[3][j] * k3 + w0[4][j] * k4;
+      for (int j = 0; j < 4; ++j) o[j] = dot5(w0[0][j], w0[1][j], w0[2][j], w0[3][j], w0[4][j], k0, k1, k2, k3, k4);
       if (y1 == 0) {                                        // lpyr_dec.py:195
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] += w0[2][j] * k1 + w0[3][j] * k0;
+        for (int j = 0; j < 4; ++j) o[j] += dot2(w0[2][j], w0[3][j], k1, k0);
       }
       if (y1 == a.H1 - 1) {                                 // :196-199
         if (a.H & 1) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] += w0[2][j] * k3 + w0[1][j] * k4;
+          for (int j = 0; j < 4; ++j) o[j] += dot2(w0[2][j], w0[1][j], k3, k4);
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] += w0[3][j] * k4;
+          for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaf(w0[3][j], k4, o[j]);
         }
       }
       if (own && y1 >= 2 * r2a && y1 < 2 * r2b) *reinterpret_cast<float4*>(out1 + (int64_t)y1 * a.W1 + c1) = make_float4(o[0], o[1], o[2], o[3]);
@@ -242,12 +250,12 @@ __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
     }
     // second level, horizontal pass: level-(l+2) column 2v reads level-(l+1) columns 4v-2 .. 4v+2, column 2v+1 reads 4v .. 4v+4
     const float l2 = __shfl_up(o[2], 1, 64), l3 = __shfl_up(o[3], 1, 64), rr0 = __shfl_down(o[0], 1, 64);
-    hr[0] = l2 * k0 + l3 * k1 + o[0] * k2 + o[1] * k3 + o[2] * k4;
-    hr[1] = o[0] * k0 + o[1] * k1 + o[2] * k2 + o[3] * k3 + rr0 * k4;
-    if (first1) hr[0] += o[0] * k1 + o[1] * k0;             // lpyr_dec.py:205 on level l+1
+    hr[0] = dot5(l2, l3, o[0], o[1], o[2], k0, k1, k2, k3, k4);
+    hr[1] = dot5(o[0], o[1], o[2], o[3], rr0, k0, k1, k2, k3, k4);
+    if (first1) hr[0] += dot2(o[0], o[1], k1, k0);          // lpyr_dec.py:205 on level l+1
     if (last1) {                                            // column W2-1 = 2v+1 (W1 % 8 == 0); sic: row parity (:206-209)
-      if (a.H1 & 1) hr[1] += o[3] * k3 + o[2] * k4;
-      else hr[1] += o[3] * k4;
+      if (a.H1 & 1) hr[1] += dot2(o[3], o[2], k3, k4);
+      else hr[1] = __builtin_fmaf(o[3], k4, hr[1]);
     }
   };
 
@@ -263,18 +271,18 @@ __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
     l1row(2 * r2 + 2, w2[4]);
     float o2[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) o2[j] = w2[0][j] * k0 + w2[1][j] * k1 + w2[2][j] * k2 + w2[3][j] * k3 + w2[4][j] * k4;
+    for (int j = 0; j < 2; ++j) o2[j] = dot5(w2[0][j], w2[1][j], w2[2][j], w2[3][j], w2[4][j], k0, k1, k2, k3, k4);
     if (r2 == 0) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) o2[j] += w2[2][j] * k1 + w2[3][j] * k0;
+      for (int j = 0; j < 2; ++j) o2[j] += dot2(w2[2][j], w2[3][j], k1, k0);
     }
     if (r2 == a.H2 - 1) {
       if (a.H1 & 1) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) o2[j] += w2[2][j] * k3 + w2[1][j] * k4;
+        for (int j = 0; j < 2; ++j) o2[j] += dot2(w2[2][j], w2[1][j], k3, k4);
       } else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) o2[j] += w2[3][j] * k4;
+        for (int j = 0; j < 2; ++j) o2[j] = __builtin_fmaf(w2[3][j], k4, o2[j]);
       }
     }
     if (own) *reinterpret_cast<float2*>(out2 + (int64_t)r2 * a.W2 + 2 * v) = make_float2(o2[0], o2[1]);

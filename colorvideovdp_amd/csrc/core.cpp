@@ -322,9 +322,9 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
   const size_t P0 = (size_t)h->lv[0].P;
   h->hist_off = h->hist_shadow_off = off;
   if (c.is_video && c.filter_len > 1) {
-    const size_t hist = align_up((size_t)2 * 3 * (c.filter_len - 1) * c.batch * P0);
+    const size_t hist = align_up((size_t)2 * 3 * (fir_kernel_len(c.filter_len) - 1) * c.batch * P0);
     off += hist;
-    if (!fir_has_register_window(c.filter_len)) { h->hist_shadow_off = off; off += hist; }  // generic-FL path double-buffers the tail
+    if (!fir_has_register_window(fir_kernel_len(c.filter_len))) { h->hist_shadow_off = off; off += hist; }  // generic-FL path double-buffers the tail
   }
   {
     // off by default: since the kernels were tuned, overlapping the band stage of block k with FIR + reduce of block
@@ -447,8 +447,10 @@ static int process_block_impl(cvvdp_handle* h, const void* t, const void* r, int
   if (!t || !r || !st || !sr || raw_first < 0) return fail(h, CVVDP_E_ARG, "bad frame arguments");
   if (n_frames < 1 || n_frames > c.block_frames) return fail(h, CVVDP_E_ARG, "n_frames out of range");
   if (q_frame_offset < 0 || q_frame_offset + n_frames > c.n_frames) return fail(h, CVVDP_E_ARG, "frame offset out of range");
-  const int fl = c.filter_len;
-  if (fl > 1 && !hist_src) return fail(h, CVVDP_E_ARG, "hist_src missing");
+  const int fl_clip = c.filter_len;
+  if (fl_clip > 1 && !hist_src) return fail(h, CVVDP_E_ARG, "hist_src missing");
+  // the kernels may run a longer filter with zero taps in front (fir_kernel_len): `pad` extra, weightless window positions
+  const int fl = fir_kernel_len(fl_clip), pad = fl - fl_clip;
   hipStream_t s = static_cast<hipStream_t>(stream);
   FirArgs f{};
   const int64_t P0 = h->lv[0].P;
@@ -482,14 +484,16 @@ static int process_block_impl(cvvdp_handle* h, const void* t, const void* r, int
       f.taps_rot[ch * CVVDP_ROT_TAPS + 32] = c.taps[ch * CVVDP_MAX_FILTER_LEN + 0];   // position fl-1 (newest) <- F[0]
     }
   }
-  for (int k = 0; k < fl - 1; ++k) {
+  for (int k = 0; k < fl_clip - 1; ++k) {
     const int e = hist_src[k];
-    if (e >= 32767 || e < -(fl - 1)) return fail(h, CVVDP_E_ARG, "hist_src[%d] = %d out of range", k, e);
+    if (e >= 32767 || e < -(fl_clip - 1)) return fail(h, CVVDP_E_ARG, "hist_src[%d] = %d out of range", k, e);
     if (e < 0 && c.raw_halo) return fail(h, CVVDP_E_ARG, "hist_src[%d] refers to the DKL tail, but the clip was configured with raw_halo", k);
-    f.hist_src[k] = (int16_t)e;
+    f.hist_src[pad + k] = (int16_t)(e >= 0 ? e : e - pad);     // the kernel's tail has `pad` more (older) slots in front
   }
+  for (int k = 0; k < pad; ++k)     // weightless positions: any finite frame will do -- the oldest real entry, or the tail's own slot
+    f.hist_src[k] = (fl_clip > 1 && hist_src[0] >= 0) ? (int16_t)hist_src[0] : (int16_t)(-1 - k);
   f.halo_run = fl > 1 && raw_first >= fl - 1;
-  for (int k = 0; k < fl - 1 && f.halo_run; ++k) f.halo_run = hist_src[k] == raw_first - (fl - 1) + k;
+  for (int k = 0; k < fl - 1 && f.halo_run; ++k) f.halo_run = f.hist_src[k] == raw_first - (fl - 1) + k;
   {
     ProfScope ps(h, CVVDP_PROF_FIR, s);
     launch_fir(f, h->ws + h->hist_shadow_off, s);
@@ -571,7 +575,7 @@ int cvvdp_debug_buffer(cvvdp_handle* h, int32_t which, int32_t level, void** dev
   switch (which) {
     case CVVDP_BUF_HIST:
       if (!h->c.is_video) return fail(h, CVVDP_E_STATE, "no temporal history for images");
-      *dev_ptr = h->ws + h->hist_off; *n_floats = (size_t)2 * 3 * (h->c.filter_len - 1) * h->c.batch * h->lv[0].P; break;
+      *dev_ptr = h->ws + h->hist_off; *n_floats = (size_t)2 * 3 * (fir_kernel_len(h->c.filter_len) - 1) * h->c.batch * h->lv[0].P; break;
     case CVVDP_BUF_GPYR: *dev_ptr = h->ws + lv.g_off; *n_floats = (size_t)2 * h->nch * h->items_cap * lv.P; break;
     case CVVDP_BUF_DDUMP:
       if (!h->c.debug_dump) return fail(h, CVVDP_E_STATE, "debug_dump not enabled");

@@ -343,3 +343,29 @@ def test_reference_video_example_blur_over_time():
     # the same clip resident on the device (64-frame blocks, raw-halo route) gives the same features bit for bit
     jod_d, stats_d = met.predict(torch.from_numpy(test).cuda(), torch.from_numpy(ref).cuda(), dim_order="HWCF", frames_per_second=fps)
     np.testing.assert_array_equal(stats_d["Q_per_ch"], stats["Q_per_ch"])
+
+
+@pytest.mark.parametrize("fps", [16, 40, 72, 100, 128])
+def test_filter_lengths_without_their_own_kernel(fps):
+    """Frame rates whose filter length has no register-window instantiation run on the next longer kernel with zero taps
+    in front (16 -> 5 taps on the 7-tap kernel, 40 -> 11/13, 72 -> 19/25, 100 -> 27/31); 128 fps (33 taps) takes the generic
+    kernel.  Against the oracle, and bit-exact over block sizes and padding modes."""
+    import colorvideovdp_amd as cv
+    from oracle import cvvdp_oracle as orc
+    rng = np.random.default_rng(fps)
+    F, H, W = 14, 48, 80
+    y, x = np.mgrid[0:H, 0:W]
+    ref = np.stack([np.stack([0.5 + 0.3 * np.sin(2 * np.pi * (2 * x / W + f / 9.0) + c) * np.cos(2 * np.pi * y / H) for c in range(3)]) for f in range(F)], axis=1)[None]
+    test = np.clip(ref + 0.05 * rng.standard_normal(ref.shape), 0, 1).astype(np.float32)
+    ref = np.clip(ref, 0, 1).astype(np.float32)
+    for pad in ("replicate", "symmetric"):
+        _, ostats = orc.Oracle("standard_fhd", temp_padding=pad).predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
+        qs = []
+        for nb in (None, 3):
+            for dev in (False, True):
+                t, r = (torch.from_numpy(test).cuda(), torch.from_numpy(ref).cuda()) if dev else (test, ref)
+                _, st = cv.cvvdp(display_name="standard_fhd", temp_padding=pad, block_frames=nb).predict(t, r, dim_order="BCFHW", frames_per_second=fps)
+                qs.append(st["Q_per_ch"])
+        np.testing.assert_allclose(qs[0], ostats["Q_per_ch"], rtol=2e-4, atol=2e-6)
+        for q in qs[1:]:
+            np.testing.assert_array_equal(qs[0], q)

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
   // Window of FL + U - 1 entries: a chunk of U frames is appended at static positions FL-1 .. FL+U-2, the U
   // outputs read statically shifted sub-windows, and the window is shifted by U once per chunk (the
   // per-frame shift of FL*3*V registers was a third of this kernel's VALU work).
-  constexpr int U = (FL <= 17 && V == 1) ? 4 : 1;   // measured on 4K/60: V=1,U=4 8.4 ms; V=2,U=1 9.0 ms; V=2,U=4 12 ms (212 VGPRs)
+  constexpr int U = (V == 1) ? 4 : 1;   // measured on 4K/60: V=1,U=4 8.4 ms; V=2,U=1 9.0 ms; V=2,U=4 12 ms (212 VGPRs)
   constexpr int WL = FL + U - 1;
   float w[3][WL][V];
   // ---- prologue: window positions 0..FL-2 (history / temporal padding)

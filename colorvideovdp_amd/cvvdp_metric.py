@@ -16,7 +16,6 @@ Differences that are deliberate:
 """
 import ctypes
 import json
-import logging
 import math
 
 import numpy as np

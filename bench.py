@@ -162,11 +162,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # test hooks: CVVDP_BENCH_DEVICE pins every rank to one GPU and CVVDP_BENCH_BACKEND=gloo replaces RCCL, so that the
+    # multi-rank path (shard plan, halo frames, all-gather, rank-0 JSON) can be exercised on a single-GPU box
+    dev_index = int(os.environ.get("CVVDP_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("CVVDP_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group(backend)
 
     import colorvideovdp_amd as cv
     from colorvideovdp_amd.sharding import plan_frame_shard

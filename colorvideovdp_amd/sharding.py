@@ -28,8 +28,12 @@ def all_gather_frames(q_local, n_frames, group=None):
     cap = (n_frames + world - 1) // world
     send = torch.zeros((B, C, cap, L), dtype=q_local.dtype, device=q_local.device)
     send[:, :, :q_local.shape[2]] = q_local
+    dev = send.device
+    if send.is_cuda and dist.get_backend(group) == "gloo":   # gloo has no all_gather on device tensors: the shards are tiny
+        send = send.cpu()
     recv = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(recv, send, group=group)
+    recv = [x.to(dev) for x in recv]
     parts = []
     for r in range(world):
         _, cnt = plan_frame_shard(n_frames, r, world)

@@ -1,0 +1,5 @@
+// K0+K1 (temporal_impl.h) instantiated for one sample format.
+#include "temporal_impl.h"
+namespace cvvdp {
+void launch_fir_u16(const FirArgs& a, float* hist_shadow, hipStream_t s) { launch_fir_typed<CVVDP_U16>(a, hist_shadow, s); }
+}  // namespace cvvdp

@@ -303,9 +303,9 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     // per row, so there must still be enough blocks to fill 256 CUs x 3.  Video: sized for the nominal 64-frame block
     // (the split must not depend on the actual block size, or per-frame sums would round differently per block size):
     // at most 384 rows, and no more segments than needed for ~768 blocks (4K: 360 rows at levels 0 and 1 = 3 % halo,
-    // 180 at level 2).  Images have one frame per launch: shorter segments, down to 16 rows.
+    // 180 at level 2).  Images have one item per batch entry and launch: as many segments as it takes, down to 16 rows.
     {
-      const int nominal = c.is_video ? 64 : 16, target = c.is_video ? 768 : 1536, max_rows = c.is_video ? 384 : 256;
+      const int nominal = c.is_video ? 64 : 1, target = 768, max_rows = c.is_video ? 384 : 256;   // an image launch holds exactly `batch` items
       const int per_seg = lv.n_strip * nominal * c.batch;
       const int want = (target + per_seg - 1) / per_seg;
       const int lo = (H + max_rows - 1) / max_rows, hi = std::max(lo, (H + 15) / 16);

@@ -54,7 +54,7 @@ class Clip(C.Structure):
         ("block_frames", C.c_int32),
         ("heatmap", C.c_int32),
         ("debug_dump", C.c_int32),
-        ("raw_halo", C.c_int32), ("reserved", C.c_int32),
+        ("raw_halo", C.c_int32), ("total_frames", C.c_int32),
         ("taps", C.c_float * (4 * MAX_FILTER_LEN)),
         ("csf_rows", C.c_float * (MAX_LEVELS * 4 * CSF_NODES)),
     ]

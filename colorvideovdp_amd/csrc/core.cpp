@@ -305,7 +305,10 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     // at most 384 rows, and no more segments than needed for ~768 blocks (4K: 360 rows at levels 0 and 1 = 3 % halo,
     // 180 at level 2).  Images have one item per batch entry and launch: as many segments as it takes, down to 16 rows.
     {
-      const int nominal = c.is_video ? 64 : 1, target = 768, max_rows = c.is_video ? 384 : 256;   // an image launch holds exactly `batch` items
+      // video: the nominal block is 64 frames, or the whole clip if that is shorter (total_frames is the same for every
+      // block and shard of a clip); an image launch holds exactly `batch` items
+      const int clip_frames = c.total_frames > 0 ? c.total_frames : 64;
+      const int nominal = c.is_video ? std::min(64, clip_frames) : 1, target = 768, max_rows = c.is_video ? 384 : 256;
       const int per_seg = lv.n_strip * nominal * c.batch;
       const int want = (target + per_seg - 1) / per_seg;
       const int lo = (H + max_rows - 1) / max_rows, hi = std::max(lo, (H + 15) / 16);

@@ -313,7 +313,7 @@ class cvvdp(vq_metric):
             C = probe_t.shape[1]
         # The clip description (temporal taps, CSF rows per band, block size) depends only on the geometry: repeated
         # calls on clips of the same shape reuse it, so the first kernel is not held back by ~0.4 ms of host set-up.
-        key = (height, width, first, count, B, C, is_image, None if is_image else float(vs.get_frames_per_second()), self.heatmap,
+        key = (height, width, N_total, first, count, B, C, is_image, None if is_image else float(vs.get_frames_per_second()), self.heatmap,
                bool(self.debug_dump), self.block_frames, self.gpu_mem, float(self.pix_per_deg), id(self.parameters), id(self.csf_table),
                self._host_resident(vs))
         cached = getattr(self, "_clip_cache", None)
@@ -326,6 +326,7 @@ class cvvdp(vq_metric):
             clip.batch, clip.channels, clip.height, clip.width = B, C, height, width
             clip.is_video, clip.n_frames, clip.n_levels = int(not is_image), count, L
             clip.first_frame = first
+            clip.total_frames = N_total
             clip.heatmap = _capi.HEATMAP[self.heatmap]
             clip.debug_dump = int(self.debug_dump)
             # device-resident clips: later blocks re-read their fl-1 predecessor frames (like a shard's halo) instead of

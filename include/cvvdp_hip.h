@@ -100,7 +100,8 @@ typedef struct cvvdp_clip {
   int32_t debug_dump;           /* 1: keep per-pixel D of every band in the workspace (tests) */
   int32_t raw_halo;             /* 1: every block is handed its filter_len-1 predecessor frames as raw frames (hist_src >= 0),
                                    so no DKL tail is kept between blocks; 0: later blocks read the tail (hist_src < 0) */
-  int32_t reserved;
+  int32_t total_frames;         /* frames of the whole clip (all shards); 0 = unknown.  Sizes the band kernels' row segments:
+                                   the same for every block and shard of a clip, so results stay bit-identical */
   float taps[4 * CVVDP_MAX_FILTER_LEN];                             /* F[c][k], not flipped */
   float csf_rows[CVVDP_MAX_LEVELS * 4 * CVVDP_CSF_NODES];           /* [band][ch][node] log10 S */
 } cvvdp_clip;

@@ -90,7 +90,8 @@ SYMBOLS = {
     "cvvdp_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
 }
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcvvdp_hip.so")
+# CVVDP_LIB: development hook (kernel variants built side by side are benchmarked against each other); unset = the in-tree library
+LIB_PATH = os.environ.get("CVVDP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcvvdp_hip.so")
 _lib = None
 
 

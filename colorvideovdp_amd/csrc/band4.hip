@@ -8,19 +8,26 @@
 //   block <-> strip of 240 interior columns (+8 aligned halo columns each side), marching down a row
 //             segment exactly like k_band.
 //
-// Two barriers per row.  Global loads for row r+1 (coarse rows for the expand, g prefetch) are issued in
-// the second phase of row r, behind ~100 FMAs of blur, so HBM latency is off the critical path:
+// Two barriers per row; every row index is wave-uniform (SALU address arithmetic), the loop is unrolled over
+// an even/odd row pair so that the expand's row parity and the two g-row register sets are static:
 //
 //   phase 1:  pooling stage of the row finished last iteration (reads s_q of all channels, s_d)
 //             contrast/CSF stage of row r (reads s_ve, s_lum; writes s_m and the s_d ring)
+//             vertical expand of row r+1 from the rolling 3-row coarse window -> s_ve
 //   barrier
-//   phase 2:  13-tap horizontal blur (5 ds_read_b128), 13-row register window, vertical blur,
-//             Mq = safe_pow(blur*10^mask_c, q_c) -> s_q ; luminance terms of row r+1 -> s_lum ;
-//             vertical expand of row r+1 (r+2 for the luminance planes) -> s_ve ; prefetch g
+//   phase 2:  loads: ONE coarse row (the window's next row) and the g rows of row r+2 (into the registers row r
+//             just left: two static register sets, no copies); luminance terms of row r+1 -> s_lum;
+//             13-tap horizontal blur (5 ds_read_b128), 13-row register window, vertical blur,
+//             Mq = (blur*10^mask_c + eps)^q_c -> s_q
 //   barrier
 //
+// Every lane issues every load on every row (clamped addresses), so the number of loads in flight is the same on
+// every path and the compiler waits with exact vmcnt(N) counts: coarse row first, then the two g rows, which
+// therefore stay in flight for two whole rows.
+//
 // Image-edge halo columns are produced by the in-image lanes as mirrored LDS writes (reflect padding
-// of the blur), halo rows by evaluating the reflected row.
+// of the blur), halo rows by evaluating the reflected row (the coarse window follows the row index up or down).
+#include <type_traits>
 #include "kernels.h"
 
 namespace cvvdp {
@@ -34,10 +41,6 @@ constexpr int B4_VE = 136;         // s_ve row: element 4+i = coarse column cb+i
 struct f4 { float v[4]; };
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float4 ld_stream4(const float* p) {   // read-once data: nontemporal, stays out of L2
-  const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
-  return make_float4(q.x, q.y, q.z, q.w);
-}
 
 __device__ __forceinline__ f4 lds_read4(const float* p) {
   const float4 q = *reinterpret_cast<const float4*>(p);
@@ -56,18 +59,19 @@ __device__ __forceinline__ int refl(int i, int n) {
 template <int NCH, bool HEAT>
 __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   constexpr int NP = 2 * NCH;
-  // s_ve is a ring of two rows (row parity): the luminance planes (0, 1; wave 0) run TWO rows ahead so that all
-  // waves can derive the per-column luminance terms of row r+1 (s_lum) during phase 2 of row r.
+  // s_ve is a ring of two rows (row parity): row r+1 is written during phase 1 of row r, so that phase 2 can derive
+  // the per-column luminance terms of row r+1 (s_lum) from its luminance planes (0, 1).
   __shared__ __attribute__((aligned(16))) float2 s_ve[2][NP][B4_VE / 2];   // float2 rows: guaranteed 8-byte aligned ds_read_b64
   __shared__ __attribute__((aligned(16))) float s_lum[4][256];             // 1/L_T, 1/L_R, CSF-LUT fraction, LUT byte offset
   __shared__ __attribute__((aligned(16))) float s_m[NCH][256];
   __shared__ __attribute__((aligned(16))) float s_q[NCH][256];
-  __shared__ __attribute__((aligned(16))) float s_d[B4_R + 1][NCH][B4_SW];   // lane-private ring of |T'-R'|: interior columns only
+  __shared__ __attribute__((aligned(16))) float s_d[B4_R + 1][NCH][B4_SW];   // lane-private ring of |T'-R'| + eps: interior columns only
   __shared__ __attribute__((aligned(16))) float s_h[HEAT ? NCH : 1][HEAT ? 256 : 4];   // heat-map terms of the pooled row, per channel
-  __shared__ float s_lut[NCH][CVVDP_CSF_NODES + 1];                         // [32] = [31]: lerp partner of the last node
+  __shared__ __attribute__((aligned(8))) float2 s_lut[NCH][CVVDP_CSF_NODES];           // (node value, step to the next node), log2 domain
 
   const int t = threadIdx.x;
-  const int c = t >> 6, j = t & 63;                 // channel (wave), lane
+  const int c = __builtin_amdgcn_readfirstlane(t >> 6);   // channel = wave: a scalar, so per-channel constants live in SGPRs
+  const int j = t & 63;
   const int strip = blockIdx.x, seg = blockIdx.y, item = blockIdx.z;
   const int H = a.H, W = a.W, Hc = a.Hc, Wc = a.Wc;
   const int x0 = strip * B4_SW;
@@ -75,51 +79,77 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   const bool in_img = fc0 >= 0 && fc0 < W;          // all four in or all four out (W % 4 == 0)
   const bool interior = j >= 2 && j < 62 && fc0 < W;  // columns whose result is pooled
   const int cb = (x0 - B4_HALO) / 2;                // coarse column of s_ve[.][1]
-  const int ys = seg * a.seg_h, ye = min(H, ys + a.seg_h);
+  const int ys = seg * a.seg_h, ye = min(H, ys + a.seg_h);   // ys is even (core.cpp keeps seg_h even)
 
   const int64_t P = (int64_t)H * W, Pc = (int64_t)Hc * Wc;
   const int64_t gps = (int64_t)a.items_cap * P, gcps = (int64_t)a.items_cap * Pc;
-  const float* gT = a.g + (int64_t)item * P + (2 * c) * gps;      // test plane of this channel
+  const float* gT = a.g + (int64_t)item * P + (2 * c) * gps;      // test plane of this channel (scalar base)
   const float* gR = gT + gps;                                      // reference plane
   // stage-1 role of this lane: plane 2c + (j>>5), coarse chunk j&31
   const int vp = 2 * c + (j >> 5);
   const int vch = j & 31;
   const int vcx = cb + 4 * vch;                                    // first coarse column of the chunk
-  const float* gcp = a.gc + (int64_t)item * Pc + vp * gcps;
+  const float* gcp = a.gc + (int64_t)item * Pc + (2 * c) * gcps;   // scalar base; the lane's plane / column go into the vector offset
 
-  for (int i = t; i < NCH * (CVVDP_CSF_NODES + 1); i += 64 * NCH) {
-    const int cc = i / (CVVDP_CSF_NODES + 1), k = min(i - cc * (CVVDP_CSF_NODES + 1), CVVDP_CSF_NODES - 1);
+  for (int i = t; i < NCH * CVVDP_CSF_NODES; i += 64 * NCH) {
+    const int cc = i / CVVDP_CSF_NODES, k = i - cc * CVVDP_CSF_NODES;
     // log2-domain CSF row with the constant gains folded in: S*ch_gain*band_mul = 2^(lut*log2(10) + log2(sens_mul*ch_gain*band_mul))
-    s_lut[cc][i - cc * (CVVDP_CSF_NODES + 1)] = a.lut[cc * CVVDP_CSF_NODES + k] * kLog2_10 + fast_log2(a.sens_mul * a.ch_gain[cc] * a.band_mul);
+    const float l0 = a.lut[cc * CVVDP_CSF_NODES + k] * kLog2_10 + fast_log2(a.sens_mul * a.ch_gain[cc] * a.band_mul);
+    const float l1 = a.lut[cc * CVVDP_CSF_NODES + min(k + 1, CVVDP_CSF_NODES - 1)] * kLog2_10 + fast_log2(a.sens_mul * a.ch_gain[cc] * a.band_mul);
+    s_lut[cc][k] = make_float2(l0, l1 - l0);
   }
   for (int i = t; i < 2 * NP * (B4_VE / 2); i += 64 * NCH) (&s_ve[0][0][0])[i] = make_float2(0.0f, 0.0f);   // unwritten apron elements
   __syncthreads();
   const float e0 = a.kx[0], e1 = a.kx[1], eo = a.kx[2];
-  const float ind_scale = (float)(CVVDP_CSF_NODES - 1) / (a.logL_last - a.logL_first);
-  const float qc = a.q[c], eps_qc = a.eps_q[c];
+  // lpyr_dec.py:408, interp.py:93 in the log2 domain: ind = (log10 L - first) * scale = log2 L * ind_k1 - ind_k0 (host constants)
+  const float ind_k1 = a.ind_k1, ind_k0 = a.ind_k0;
+  const float qc = a.q[c];
   const float xw0 = a.xw[0 * 4 + c], xw1 = a.xw[1 * 4 + c], xw2 = a.xw[2 * 4 + c], xw3 = a.xw[3 * 4 + c];
+  const float m1c = a.m1[c];                       // 1 - sum_k xw[k][c] * eps^q_k: the "1 +" of the mask and the eps terms of safe_pow
+  const float inv_dmax = a.inv_dmax;
 
-  // vertical half of the expand for fine row rr -> s_ve (lpyr_dec.py:229-232), split in two so that the
-  // global loads are issued a whole row-iteration before their values are needed
+  // ---- expand, vertical half (lpyr_dec.py:229-232): a rolling window of three coarse rows (my-1, my, my+1, clamped)
+  // in registers, my = row >> 1.  While the fine rows ascend inside the image (everywhere but the reflected rows at the
+  // image's top and bottom edge) an odd row shares the window of the even row before it and an even row needs ONE new
+  // coarse row, requested a row and a half earlier: each coarse row comes from HBM once.  Reflected rows reload the
+  // whole window (the loads land in the window registers directly).
   const int cx = min(max(vcx, 0), Wc - 4);
   const bool clampL = vcx < 0, clampR = vcx >= Wc;
   const bool edge_block = cb < 0 || cb + 128 > Wc;   // block-uniform: only edge strips pay for the replicate selects
-  float4 cA, cB, cC;    // coarse rows my-1, my, my+1 (clamped) of the chunk
-  auto stage1_load = [&](int rr) {
-    const int my = rr >> 1;
-    const int ya = max(my - 1, 0), yb = min(my + 1, Hc - 1);
-    cA = *reinterpret_cast<const float4*>(gcp + (int64_t)ya * Wc + cx);
-    cB = *reinterpret_cast<const float4*>(gcp + (int64_t)my * Wc + cx);
-    cC = *reinterpret_cast<const float4*>(gcp + (int64_t)yb * Wc + cx);
+  const float* gcl = gcp + (int64_t)(j >> 5) * gcps + cx;         // the lane's plane and chunk (64-bit: plane strides can pass 4 GB)
+  float4 cA, cB, cC;        // coarse rows my-1, my, my+1 (clamped) of the chunk
+  v4f cN = 0.0f;            // the next row up, in flight (hand-managed load, see STREAM LOADS)
+  auto coarse_load = [&](int row) -> float4 {
+    return *reinterpret_cast<const float4*>(gcl + (int64_t)row * Wc);
   };
-  auto stage1_finish = [&](int rr, int buf) {
-    if (edge_block && (clampL || clampR)) {      // replicate column 0 / Wc-1 for chunks left / right of the image
-      const float ra = clampL ? cA.x : cA.w, rb = clampL ? cB.x : cB.w, rc = clampL ? cC.x : cC.w;
-      cA = make_float4(ra, ra, ra, ra); cB = make_float4(rb, rb, rb, rb); cC = make_float4(rc, rc, rc, rc);
+  auto replicate = [&](float4 v) -> float4 {     // replicate column 0 / Wc-1 for chunks left / right of the image
+    if (edge_block && (clampL || clampR)) {
+      const float rv = clampL ? v.x : v.w;
+      v = make_float4(rv, rv, rv, rv);
+    }
+    return v;
+  };
+  // request what the window of fine row q needs.  FAST (rows q-1 and q inside the image, the window holds row q-1): an odd
+  // row shares its predecessor's window, an even row needs the next coarse row up.  Otherwise the whole window is reloaded.
+  auto coarse_issue = [&](int q, auto odd, auto fast) {
+    if constexpr (!decltype(fast)::value) {
+      const int my = min(refl(q, H), H - 1) >> 1;
+      cA = coarse_load(max(my - 1, 0));
+      cB = coarse_load(my);
+      cC = coarse_load(min(my + 1, Hc - 1));
+    }
+  };
+  // move the window to the row requested last (same odd / fast as its coarse_issue) and write its vertically expanded row to s_ve[buf]
+  auto coarse_finish = [&](int buf, auto odd, auto fast) {
+    if constexpr (decltype(fast)::value) {
+      if constexpr (!decltype(odd)::value) { cA = cB; cB = cC; cC = replicate(make_float4(cN.x, cN.y, cN.z, cN.w)); }
+      else { cB = replicate(cB); cC = replicate(cC); }   // idempotent; the first rolling step finishes a row that was reloaded raw
+    } else {
+      cA = replicate(cA); cB = replicate(cB); cC = replicate(cC);
     }
     const float m0[4] = {cA.x, cA.y, cA.z, cA.w}, m1[4] = {cB.x, cB.y, cB.z, cB.w}, m2[4] = {cC.x, cC.y, cC.z, cC.w};
     float o[4];
-    if (rr & 1) {
+    if constexpr (decltype(odd)::value) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = m1[i] * eo + m2[i] * eo;
     } else {
@@ -156,13 +186,13 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
       const float eyT = yT[e - 1] * lwa + yT[e] * lwb + yT[e + 1] * lwc;
       const float eyR = yR[e - 1] * lwa + yR[e] * lwb + yR[e + 1] * lwc;
       const float Lt = fmaxf(eyT, 0.01f), Lr = fmaxf(eyR, 0.01f);              // lpyr_dec.py:394
-      float ind = (fast_log2(Lr) * kLog10_2 - a.logL_first) * ind_scale;       // lpyr_dec.py:408, interp.py:93
-      ind = fminf(fmaxf(ind, 0.0f), (float)(CVVDP_CSF_NODES - 1));
+      float ind = fast_log2(Lr) * ind_k1 - ind_k0;
+      ind = __builtin_amdgcn_fmed3f(ind, 0.0f, (float)(CVVDP_CSF_NODES - 1));  // clamp (interp.py:93)
       const int i0 = (int)ind;
       s_lum[0][col] = fast_rcp(Lt);
       s_lum[1][col] = fast_rcp(Lr);
-      s_lum[2][col] = ind - (float)i0;
-      s_lum[3][col] = __int_as_float(i0 * 4);
+      s_lum[2][col] = __builtin_amdgcn_fractf(ind);                            // ind >= 0: ind - floor(ind)
+      s_lum[3][col] = __int_as_float(i0 * 8);                                  // byte offset into a float2 LUT row
     }
   };
 
@@ -172,31 +202,32 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   // static register indices and no 13-way switch / PHI copies are needed.
   typedef float v32f __attribute__((ext_vector_type(32)));
   v32f winA = 0.0f, winB = 0.0f;   // columns (0,1) and (2,3) interleaved: element 2s+i = slot s of column i
+  // horizontal taps carry the mask gain 10^mask_c (the blur is linear; a.blur_h is pre-scaled on the host so that the
+  // taps stay in SGPRs): Mq needs no extra multiply
   v2f be[6], bo[6];
 #pragma unroll
-  for (int m = 0; m < 6; ++m) { be[m] = v2f{a.blur[2 * m], a.blur[2 * m + 1]}; bo[m] = v2f{a.blur[2 * m + 1], a.blur[2 * m + 2]}; }
-  const float b0 = a.blur[0], b12 = a.blur[12];
+  for (int m = 0; m < 6; ++m) { be[m] = v2f{a.blur_h[2 * m], a.blur_h[2 * m + 1]}; bo[m] = v2f{a.blur_h[2 * m + 1], a.blur_h[2 * m + 2]}; }
+  const float b0 = a.blur_h[0], b12 = a.blur_h[12];
   float wr[B4_BW];     // wr[s] = weight of slot s for the NEXT row to be written into slot 0
 #pragma unroll
   for (int k = 0; k < B4_BW; ++k) wr[k] = a.blur[(k + B4_BW - 1) % B4_BW];
   float acc = 0.0f;
 
-  // pooling stage of centre row y (cvvdp_metric.py:849-856, 722): needs s_q of all channels and s_d
-  auto stage3c = [&](int y) {
-    const int ds = ((y % (B4_R + 1)) + (B4_R + 1)) % (B4_R + 1);
+  // pooling stage of centre row y (cvvdp_metric.py:849-856, 722): needs s_q of all channels and s_d (ring slot k7)
+  auto stage3c = [&](int y, int k7) {
     const f4 q0 = lds_read4(&s_q[0][4 * j]), q1 = lds_read4(&s_q[1][4 * j]), q2 = lds_read4(&s_q[2][4 * j]);
     f4 q3 = f4{{0.0f, 0.0f, 0.0f, 0.0f}};
     if constexpr (NCH == 4) q3 = lds_read4(&s_q[3][4 * j]);
-    const f4 d = lds_read4(&s_d[ds][c][4 * j - B4_HALO]);
+    const f4 d = lds_read4(&s_d[k7][c][4 * j - B4_HALO]);
     float D[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float M = q0.v[i] * xw0 + q1.v[i] * xw1 + q2.v[i] * xw2 + q3.v[i] * xw3;     // cvvdp_metric.py:758-760
-      // Du = X/(1+M); D = dmax*Du/(dmax+Du) = dmax*X / (dmax*(1+M) + X): one reciprocal (:855-856, :949-950)
-      const float X = fast_pow(d.v[i] + kEps, a.mask_p) - a.eps_p;
-      D[i] = a.dmax * X * fast_rcp(a.dmax + a.dmax * M + X);
-      const float de = D[i] + kEps;
-      acc += de * de - kEps * kEps;
+      // 1 + M, M = sum_k xw[k][c] * ((blur_k*10^mask_c + eps)^q_k - eps^q_k)     (cvvdp_metric.py:758-760, :849)
+      const float M1 = q3.v[i] * xw3 + (q2.v[i] * xw2 + (q1.v[i] * xw1 + (q0.v[i] * xw0 + m1c)));
+      // Du = X/(1+M); D = dmax*Du/(dmax+Du) = X / ((1+M) + X/dmax): one reciprocal (:855-856, :949-950)
+      const float X = fast_pow(d.v[i], a.mask_p) - a.eps_p;      // s_d holds |T'-R'| + eps
+      D[i] = X * fast_rcp(X * inv_dmax + M1);
+      acc += D[i] * (D[i] + 2.0f * kEps);                        // (D+eps)^2 - eps^2
     }
     if (a.ddump) *reinterpret_cast<float4*>(a.ddump + (int64_t)c * a.items_cap * P + (int64_t)item * P + (int64_t)y * W + fc0) =
         make_float4(D[0], D[1], D[2], D[3]);
@@ -222,92 +253,117 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     }
   };
 
-  // ---- prologue: expand rows (luminance: two of them), g prefetch and luminance terms for the first row
-  const int ahead = c == 0 ? 2 : 1;                  // wave-uniform
-  int r = ys - B4_R;
-  int rr = refl(r, H);
-  stage1_load(rr);
-  float4 pT = make_float4(0, 0, 0, 0), pR = make_float4(0, 0, 0, 0);
-  // g rows are streamed from HBM two rows ahead.  Every lane issues every load (out-of-image halo lanes and
-  // rows past the segment read a clamped, valid address) so that each iteration has the same five loads in
-  // flight and the waits can be exact vmcnt(N) counts instead of a full drain.
-  const int fcl = min(max(fc0, 0), W - 4);
-  float4 nT, nR;
-  {
-    pT = ld_stream4(gT + (int64_t)rr * W + fcl);
-    pR = ld_stream4(gR + (int64_t)rr * W + fcl);
-    const int r1 = refl(r + 1, H);
-    nT = ld_stream4(gT + (int64_t)r1 * W + fcl);
-    nR = ld_stream4(gR + (int64_t)r1 * W + fcl);
+  // ---- STREAM LOADS.  The g rows (two planes, nontemporal: read once) and the coarse window's next row are requested a
+  // whole row (two phases) before they are used and must stay in flight across a barrier and the other row's loads.
+  // hipcc's wait-count insertion drains the queue (vmcnt(0)) at the first use after a loop back edge, which halves the
+  // bytes in flight and leaves the kernel waiting for HBM (57 % of the wave cycles parked, measured).  So these loads
+  // are issued from inline assembly, which that pass does not track, and waited for explicitly:
+  //     even step, phase 2:  g rows of row r+2 -> p0T, p0R                      (2 loads)
+  //     odd  step, phase 2:  coarse row for the window move of row r+3 -> cN,
+  //                          g rows of row r+2 -> p1T, p1R                      (3 loads)
+  //     even step, phase 1:  needs p0*: younger loads cN, p1T, p1R  -> s_waitcnt vmcnt(3)
+  //     odd  step, phase 1:  needs p1*, cN: younger loads p0T, p0R  -> s_waitcnt vmcnt(2)
+  // Loads return in order, so any extra (compiler-issued) memory operation in between only makes these waits stricter;
+  // the destination registers are tied ("+v") from the request to the wait, and everything is drained between loops and
+  // before the epilogue (a register copy or reuse while a load is in flight would read / clobber stale data:
+  // tools/check_band4_isa.py checks the generated code for that).  Out-of-image halo lanes read a clamped, valid address.
+  const uint32_t goff = (uint32_t)min(max(fc0, 0), W - 4) * 4u;
+  v4f p0T = 0.0f, p0R = 0.0f, p1T = 0.0f, p1R = 0.0f;       // g rows of the even / odd row in flight
+#define B4_G_LOAD(dst, plane, row) \
+  asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "+v"(dst) : "v"(goff), "s"((plane) + (int64_t)(row) * W))
+#define B4_C_LOAD(dst, row) \
+  asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(gcl + (int64_t)(row) * Wc))
+#define B4_WAIT_EVEN() asm volatile("s_waitcnt vmcnt(3)" : "+v"(p0T), "+v"(p0R))
+#define B4_WAIT_ODD() asm volatile("s_waitcnt vmcnt(2)" : "+v"(p1T), "+v"(p1R), "+v"(cN))
+// (the builtin, not asm: the compiler's own wait-count bookkeeping must see that nothing of ITS loads is pending either, or it
+// keeps re-waiting inside the next loop; 0x0F70 = vmcnt(0) with the other counters at their maxima on gfx9)
+#define B4_DRAIN() do { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" : "+v"(p0T), "+v"(p0R), "+v"(p1T), "+v"(p1R), "+v"(cN)); } while (0)
+  auto stream_issue = [&](int r, auto odd_row) {   // phase 2 of row r
+    (void)&p0T; (void)&p0R; (void)&p1T; (void)&p1R; (void)&cN; (void)&goff; (void)&gT; (void)&gR; (void)&gcl; (void)&W; (void)&Wc;   // (asm operands alone do not capture in a generic lambda)
+    const int r2 = min(refl(r + 2, H), H - 1);
+    if constexpr (decltype(odd_row)::value) {
+      const int rowc = min(max(((r + 3) >> 1) + 1, 0), Hc - 1);   // what the ascending window move of row r+3 needs
+      B4_C_LOAD(cN, rowc);
+      B4_G_LOAD(p1T, gT, r2);
+      B4_G_LOAD(p1R, gR, r2);
+    } else {
+      B4_G_LOAD(p0T, gT, r2);
+      B4_G_LOAD(p0R, gR, r2);
+    }
+  };
+
+  // image-edge mirror roles (see the contrast stage): left edge = lanes with fc0 = 0 / 4 (strip 0), right edge = lanes
+  // with fc0 = W-8 / W-4 (last strip); W >= 16 keeps them apart
+  const bool mir_block = strip == 0 || x0 + B4_SW >= W;
+  int mir_kind = 0, mir_base = 0;
+  if (strip == 0 && (fc0 == 0 || fc0 == 4)) { mir_kind = fc0 == 0 ? 1 : 2; mir_base = B4_HALO - (fc0 == 0 ? 1 : 4); }
+  if (fc0 == W - 8 || fc0 == W - 4) {
+    mir_kind = fc0 == W - 8 ? 1 : 2;
+    mir_base = 2 * (W - 1) - (fc0 + (fc0 == W - 8 ? 1 : 0)) - (x0 - B4_HALO);
   }
-  stage1_finish(rr, r & 1);
-  if (c == 0) {
-    const int r1 = refl(r + 1, H);
-    stage1_load(r1);
-    stage1_finish(r1, (r + 1) & 1);
+
+  // ---- prologue: window + expand of the first row, g rows of the first two rows, luminance terms of the first row
+  const int r0 = ys - B4_R, rend = ye + B4_R;
+  {
+    coarse_issue(r0, std::false_type{}, std::false_type{});        // r0 is even
+    stream_issue(r0 - 2, std::false_type{});                       // g rows of row r0
+    coarse_finish(0, std::false_type{}, std::false_type{});
+    coarse_issue(r0 + 1, std::true_type{}, std::false_type{});     // (a reload is valid for any row)
+    stream_issue(r0 - 1, std::true_type{});                        // g rows of row r0+1, coarse row for the move of row r0+2
   }
   __syncthreads();
-  lum_prep(r & 1);
+  lum_prep(0);
   __syncthreads();
 
-  for (; r < ye + B4_R; ++r) {
+  int slot = 0, k7 = 0;            // (r - r0) mod 13: blur window slot; (r - r0) mod 7: s_d ring slot
+  // one row.  Its g values sit in p0* (even row) or p1* (odd row) and are reloaded with row r+2 in phase 2.
+  // fin_fast / iss_fast: coarse-window mode of row r+1 (finished here) and of row r+2 (requested here)
+  auto step = [&](int r, auto odd_row, auto fin_fast, auto iss_fast) {
+    constexpr bool ODD = decltype(odd_row)::value;
+    (void)&p0T; (void)&p0R; (void)&p1T; (void)&p1R; (void)&cN;   // (asm operands alone do not capture in a generic lambda)
+    if constexpr (ODD) B4_WAIT_ODD(); else B4_WAIT_EVEN();
+    v4f pT, pR;
+    if constexpr (ODD) { pT = p1T; pR = p1R; } else { pT = p0T; pR = p0R; }
     // ================= phase 1
-    const int yprev = r - 1 - B4_R;                  // row whose Mq was published last iteration
-    if (interior && yprev >= ys) stage3c(yprev);
-    float m[4], d[4];
+    const int yprev = r - 1 - B4_R;                  // row whose Mq was published last iteration (ring slot k7, like row r)
+    if (interior && yprev >= ys) stage3c(yprev, k7);
     if (in_img) {
       float exT[4], exR[4];
-      expand4(s_ve[r & 1][2 * c], exT);
-      expand4(s_ve[r & 1][2 * c + 1], exR);
+      expand4(s_ve[ODD][2 * c], exT);
+      expand4(s_ve[ODD][2 * c + 1], exR);
       const f4 rLt = lds_read4(&s_lum[0][4 * j]), rLr = lds_read4(&s_lum[1][4 * j]), fr = lds_read4(&s_lum[2][4 * j]);
       const f4 lo = lds_read4(&s_lum[3][4 * j]);
       const float gt[4] = {pT.x, pT.y, pT.z, pT.w}, gr[4] = {pR.x, pR.y, pR.z, pR.w};
+      float m[4], d[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float* lp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(&s_lut[c][0]) + __float_as_int(lo.v[i]));
-        const float l0 = lp[0], l1 = lp[1];
-        const float S = fast_exp2(l0 + (l1 - l0) * fr.v[i]);                     // csf.py:49, cvvdp_metric.py:709,:836
+        const float2 ln = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(&s_lut[c][0]) + __float_as_int(lo.v[i]));
+        const float S = fast_exp2(ln.x + ln.y * fr.v[i]);                        // csf.py:49, cvvdp_metric.py:709,:836
         const float ct = fminf((gt[i] - exT[i]) * rLt.v[i], 1000.0f);            // lpyr_dec.py:402 (band gain :66 is in S)
         const float cr = fminf((gr[i] - exR[i]) * rLr.v[i], 1000.0f);
-        const float Tp = ct * S, Rp = cr * S;
-        m[i] = fminf(fabsf(Tp), fabsf(Rp));                                      // cvvdp_metric.py:845
-        d[i] = fabsf(Tp - Rp);
+        m[i] = fminf(fabsf(ct), fabsf(cr)) * S;                                  // min(|T'|,|R'|), T' = ct*S (cvvdp_metric.py:845)
+        d[i] = fabsf(ct - cr) * S + kEps;                                        // |T'-R'| + eps (:855, safe_pow)
       }
       lds_write4(&s_m[c][4 * j], m);
-      const int ds = ((r % (B4_R + 1)) + (B4_R + 1)) % (B4_R + 1);
-      if (interior) lds_write4(&s_d[ds][c][4 * j - B4_HALO], d);
-      // reflect padding of the blur at the image's left/right edge: mirror columns 1..6 / W-7..W-2
-      if (fc0 < 8) {                                  // strip 0, lanes holding columns 0..7
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int x = fc0 + i;
-          if (x >= 1 && x <= B4_R) s_m[c][B4_HALO - x] = m[i];               // column -x
-        }
-      }
-      if (fc0 + 8 >= W) {                             // lanes holding columns W-8..W-1
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int x = fc0 + i;
-          const int idx = 2 * (W - 1) - x - (x0 - B4_HALO);                  // column 2(W-1)-x
-          if (x <= W - 2 && x >= W - 1 - B4_R && idx < 256) s_m[c][idx] = m[i];
+      if (interior) lds_write4(&s_d[k7][c][4 * j - B4_HALO], d);
+      // reflect padding of the blur at the image's left/right edge: mirror columns 1..6 / W-7..W-2.  Two lanes per
+      // edge hold them: the outer one mirrors its columns 1..3 (kind 1), the inner one its columns 0..2 (kind 2), to
+      // three consecutive descending LDS elements
+      if (mir_block) {
+        if (mir_kind != 0) {
+          const float v0 = mir_kind == 1 ? m[1] : m[0], v1 = mir_kind == 1 ? m[2] : m[1], v2 = mir_kind == 1 ? m[3] : m[2];
+          float* dst = &s_m[c][mir_base];
+          dst[0] = v0; dst[-1] = v1; dst[-2] = v2;
         }
       }
     }
+    coarse_finish(ODD ? 0 : 1, std::integral_constant<bool, !ODD>{}, fin_fast);   // vertical expand of row r+1 (its coarse row was requested a phase ago)
     __syncthreads();
     // ================= phase 2
-    // issue the global loads right after the barrier: coarse rows are consumed at the end of this phase
-    // (-> s_ve), the g rows a whole iteration later
-    const bool more = r + 1 < ye + B4_R;
     if (yprev >= ys) heat_row(yprev);                 // terms of row yprev were published in phase 1
-    const int rs = min(refl(r + ahead, H), H - 1);
-    stage1_load(rs);
-    pT = nT; pR = nR;                                 // row r+1, requested a whole iteration ago
-    {
-      const int r2 = min(refl(r + 2, H), H - 1);
-      nT = ld_stream4(gT + (int64_t)r2 * W + fcl);
-      nR = ld_stream4(gR + (int64_t)r2 * W + fcl);
-    }
-    if (more) lum_prep((r + 1) & 1);                  // luminance planes of row r+1 were published an iteration ago
+    coarse_issue(r + 2, odd_row, iss_fast);           // row r+2 has the parity of row r
+    stream_issue(r, odd_row);
+    lum_prep(ODD ? 0 : 1);                            // luminance planes of row r+1 were published in phase 1
     const int yc = r - B4_R;
     if (interior) {
       // horizontal 13-tap blur of 4 adjacent outputs on packed fp32 FMAs (v_pk_fma_f32: two taps per
@@ -329,7 +385,6 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
         h[3] = (s3.x + b0 * xp[2].y) + s3.y;
       }
       float v[4];
-      const int slot = (r - (ys - B4_R)) % B4_BW;          // wave-uniform
       winA[2 * slot] = h[0]; winA[2 * slot + 1] = h[1]; winB[2 * slot] = h[2]; winB[2 * slot + 1] = h[3];
       // weight of slot s when the newest row sits in `slot`: window position j = (s - slot - 1) mod 13 -> wr[]
       // is kept rotated so that wr[s] is exactly that weight; columns (0,1) and (2,3) share one packed FMA
@@ -346,7 +401,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
       if (yc >= ys) {
         float Mq[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Mq[i] = fast_pow(fabsf(v[i] * a.mask_c10) + kEps, qc) - eps_qc;   // cvvdp_metric.py:849
+        for (int i = 0; i < 4; ++i) Mq[i] = fast_pow(v[i] + kEps, qc);   // cvvdp_metric.py:849; "- eps^q" is inside m1c
         lds_write4(&s_q[c][4 * j], Mq);
       }
     }
@@ -356,11 +411,35 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
       for (int k = B4_BW - 1; k > 0; --k) wr[k] = wr[k - 1];
       wr[0] = last;
     }
-    stage1_finish(rs, (r + ahead) & 1);
+    slot = slot == B4_BW - 1 ? 0 : slot + 1;
+    k7 = k7 == B4_R ? 0 : k7 + 1;
     __syncthreads();
+  };
+
+  // Row pairs (even, odd).  Reflected rows (above the image: r < 0; at its bottom: r + 3 > H - 1) reload the coarse window
+  // row by row; in between the window rolls.  A row's window mode belongs to the row: requested in one step, finished in
+  // the next, so the first step of the rolling loop finishes a reloaded row (for an odd row the two are the same thing).
+  int r = r0;
+  bool done = false;
+  for (int pass = 0; pass < 2 && !done; ++pass) {
+    const int lim = pass == 0 ? min(rend, 0) : rend;
+    for (; r < lim; r += 2) {
+      step(r, std::false_type{}, std::false_type{}, std::false_type{});
+      if (r + 1 >= rend) { done = true; break; }
+      step(r + 1, std::true_type{}, std::false_type{}, std::false_type{});
+    }
+    B4_DRAIN();
+    if (pass == 0 && !done) {
+      for (; r < rend && r + 3 <= H - 1; r += 2) {
+        step(r, std::false_type{}, std::true_type{}, std::true_type{});    // finishes odd row r+1 (shares the window)
+        if (r + 1 >= rend) { done = true; break; }
+        step(r + 1, std::true_type{}, std::true_type{}, std::true_type{});  // finishes even row r+2: the window moves up
+      }
+      B4_DRAIN();
+    }
   }
   // ---- epilogue: pooling stage of the last centre row
-  if (interior && (ye - 1) >= ys) stage3c(ye - 1);
+  if (interior && (ye - 1) >= ys) stage3c(ye - 1, k7);    // row ye-1 = rend-7 shares the ring slot of row rend
   if constexpr (HEAT) {
     __syncthreads();
     if ((ye - 1) >= ys) heat_row(ye - 1);
@@ -373,6 +452,12 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     a.partial[((int64_t)item * nblk + (seg * a.n_strip + strip)) * 4 + c] = acc;
   }
 }
+
+#undef B4_G_LOAD
+#undef B4_C_LOAD
+#undef B4_WAIT_EVEN
+#undef B4_WAIT_ODD
+#undef B4_DRAIN
 
 void launch_band4(const BandArgs& a, hipStream_t s) {
   dim3 grid(a.n_strip, a.n_seg, a.items);

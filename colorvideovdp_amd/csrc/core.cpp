@@ -190,7 +190,17 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
     a.mask_c10 = h->p.mask_c10; a.mask_p = h->p.mask_p; a.eps_p = std::pow(kEps, h->p.mask_p);
     for (int i = 0; i < 16; ++i) a.xw[i] = h->p.xcm[i];
     a.dmax = h->p.d_max10;
-    for (int i = 0; i < 13; ++i) a.blur[i] = h->p.blur_taps[i];
+    a.inv_dmax = (float)(1.0 / (double)h->p.d_max10);
+    for (int c = 0; c < 4; ++c) {
+      double m1 = 1.0;
+      for (int k = 0; k < nch; ++k) m1 -= (double)h->p.xcm[k * 4 + c] * std::pow((double)kEps, (double)h->p.mask_q[k]);
+      a.m1[c] = (float)m1;
+    }
+    for (int i = 0; i < 13; ++i) { a.blur[i] = h->p.blur_taps[i]; a.blur_h[i] = h->p.blur_taps[i] * h->p.mask_c10; }
+    {
+      const double ind_scale = (double)(CVVDP_CSF_NODES - 1) / ((double)h->p.csf_logL_last - (double)h->p.csf_logL_first);
+      a.ind_k1 = (float)(0.30102999566398120 * ind_scale); a.ind_k0 = (float)((double)h->p.csf_logL_first * ind_scale);
+    }
     a.kx[0] = K[0] * 2.0f; a.kx[1] = K[2] * 2.0f; a.kx[2] = K[1] * 2.0f;
     a.partial = h->ws + h->partial_off;
     a.dchr = heat ? h->ws + lv.heat_off : nullptr;
@@ -296,7 +306,7 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     Level& lv = h->lv[l];
     lv.H = H; lv.W = W; lv.P = (int64_t)H * W;
     lv.blur = pad > 0 && H > pad && W > pad;
-    lv.vec4 = lv.blur && (W % 8 == 0);
+    lv.vec4 = lv.blur && (W % 8 == 0) && W >= 16 && H >= 16;   // k_band4: edge-mirror lanes apart, reflected prefetch rows inside the image
     const int sw = lv.vec4 ? kBand4StripWidth : (lv.blur ? 256 - 2 * pad : 256);
     lv.n_strip = (W + sw - 1) / sw;
     // Row segments.  Every segment recomputes 12 blur-halo rows, so segments should be long; a block marches ~2.6 us
@@ -314,6 +324,7 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
       const int lo = (H + max_rows - 1) / max_rows, hi = std::max(lo, (H + 15) / 16);
       lv.n_seg = std::min(std::max(want, lo), hi);
       lv.seg_h = (H + lv.n_seg - 1) / lv.n_seg;
+      lv.seg_h += lv.seg_h & 1;               // even: k_band4 unrolls its row loop over even/odd row pairs
       lv.n_seg = (H + lv.seg_h - 1) / lv.seg_h;
     }
     if (l + 1 < h->L && (H < 2 || W < 2)) return fail(h, CVVDP_E_ARG, "pyramid too deep for %dx%d", c.width, c.height);

@@ -118,6 +118,10 @@ struct BandArgs {
   float q[4], eps_q[4];
   float xw[16];
   float dmax;
+  float m1[4];       // k_band4: 1 - sum_k xw[k][c]*eps^q_k (the "1 +" of the mask with the eps terms of safe_pow folded in)
+  float inv_dmax;    // k_band4: 1 / dmax
+  float blur_h[13];  // k_band4: blur taps * 10^mask_c (horizontal pass)
+  float ind_k1, ind_k0;   // k_band4: CSF-LUT position = log2(L) * ind_k1 - ind_k0
   float blur[13];
   float kx[3];       // expand taps: 2*K[0], 2*K[2] (even), 2*K[1] (odd)
   float* partial;    // [items][n_strip*n_seg][4]
@@ -127,7 +131,7 @@ struct BandArgs {
   float* ddump;      // debug [4][items_cap][H*W] or null
 };
 void launch_band(const BandArgs& a, bool blur, hipStream_t s);
-void launch_band4(const BandArgs& a, hipStream_t s);   // vectorised variant: W % 8 == 0, blur on, no heat map
+void launch_band4(const BandArgs& a, hipStream_t s);   // vectorised variant: W % 8 == 0, blur on, seg_h even
 constexpr int kBand4StripWidth = 240;
 
 struct BaseArgs {

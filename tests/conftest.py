@@ -22,7 +22,7 @@ def _names(pattern):
 
 def golden_cases():
     """Array-input cases made by oracle/make_goldens.py."""
-    return [n for n in _names("*.npz") if n != "setup" and not n.startswith(("yuv", "fullsize", "kat_"))]
+    return [n for n in _names("*.npz") if n != "setup" and not n.startswith(("yuv", "fullsize", "kat_", "bench_"))]
 
 
 def yuv_cases():
@@ -45,6 +45,11 @@ def setup_vectors():
 def fullsize_cases():
     """Reference outputs on prefixes of bench.py's synthetic clips (oracle/make_goldens_fullsize.py); inputs are regenerated."""
     return _names("fullsize*.npz")
+
+
+def bench_cases():
+    """Reference outputs on the FULL clips bench.py times (oracle/make_goldens_bench.py); inputs are regenerated."""
+    return _names("bench_*.npz")
 
 
 def fullsize_inputs(g):

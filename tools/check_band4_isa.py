@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Safety check of the hand-managed stream loads in csrc/band4.hip (see STREAM LOADS there).
+
+The g-row / coarse-row loads of k_band4 are issued from inline assembly and waited for with explicit
+`s_waitcnt vmcnt(N)`; the compiler does not know that their destination registers are "in flight" in between.
+This script reads the generated assembly and checks, for every loop of every k_band4 instantiation, that no
+instruction reads or writes a destination register of a stream load between the load and the wait that covers
+it (walking each loop body twice in layout order, so that the back edge is covered; loads return in order, so
+`vmcnt(N)` retires all but the N youngest).
+
+    tools/isa_band4.sh && python tools/check_band4_isa.py [/tmp/isa/band4_new.s]
+"""
+import re
+import sys
+
+
+def regs(tok):
+    out = []
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+        if m.group(1):
+            out += list(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.append(int(m.group(3)))
+    return out
+
+
+def check_kernel(name, lines):
+    # loops = [header label line, last line that branches back to it]
+    labels = {l.split(":")[0]: i for i, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:", l)}
+    loops = []
+    for i, l in enumerate(lines):
+        m = re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            loops.append((labels[m.group(1)], i))
+    bad = 0
+    n_loads = 0
+    for lo, hi in loops:
+        body = lines[lo:hi + 1]
+        if not any("global_load_dwordx4" in l and " nt" in l for l in body):
+            continue
+        queue = []                 # in-flight loads, oldest first: (set of regs, text)
+        for it in range(2):
+            for l in body:
+                code = l.split(";")[0].strip()
+                if not code or code.endswith(":") or code.startswith("."):
+                    continue
+                op = code.split()[0]
+                m = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", code)
+                if m:
+                    n = int(m.group(1))
+                    while len(queue) > n:
+                        queue.pop(0)
+                    continue
+                touched = set(regs(code.split(None, 1)[1])) if len(code.split(None, 1)) > 1 else set()
+                for rs, txt in queue:
+                    if touched & rs:
+                        print(f"{name}: '{code}' touches v{sorted(touched & rs)} while '{txt}' is in flight")
+                        bad += 1
+                if op.startswith("global_load"):
+                    dst = set(regs(code.split(None, 1)[1].split(",")[0]))
+                    queue.append((dst, code))
+                    n_loads += it == 0
+                elif op.startswith(("global_store", "buffer_store")):
+                    queue.append((set(), code))      # stores count in vmcnt on gfx9
+    return bad, n_loads, len(loops)
+
+
+def main(path):
+    text = open(path).read().split("\n")
+    starts = [i for i, l in enumerate(text) if re.match(r"^_ZN5cvvdp7k_band4.*:\s*(;.*)?$", l)]
+    total_bad = 0
+    for s in starts:
+        e = next(i for i in range(s, len(text)) if ".end_amdhsa_kernel" in text[i] or text[i].startswith("\t.section"))
+        bad, n_loads, n_loops = check_kernel(text[s].split(":")[0], text[s:e])
+        print(f"{text[s].split(':')[0]}: {n_loops} loops, {n_loads} loads in streaming loops, {bad} violations")
+        total_bad += bad
+    return 1 if total_bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1] if len(sys.argv) > 1 else "/tmp/isa/band4_new.s"))

@@ -102,11 +102,17 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   __syncthreads();
   const float e0 = a.kx[0], e1 = a.kx[1], eo = a.kx[2];
   // lpyr_dec.py:408, interp.py:93 in the log2 domain: ind = (log10 L - first) * scale = log2 L * ind_k1 - ind_k0 (host constants)
-  const float ind_k1 = a.ind_k1, ind_k0 = a.ind_k0;
-  const float qc = a.q[c];
-  const float xw0 = a.xw[0 * 4 + c], xw1 = a.xw[1 * 4 + c], xw2 = a.xw[2 * 4 + c], xw3 = a.xw[3 * 4 + c];
-  const float m1c = a.m1[c];                       // 1 - sum_k xw[k][c] * eps^q_k: the "1 +" of the mask and the eps terms of safe_pow
-  const float inv_dmax = a.inv_dmax;
+  // Wave-uniform constants that are used as plain VALU operands are parked in VGPRs (the empty asm hides their uniformity):
+  // the loop needs ~110 SGPRs (13 + 14 blur taps, row arithmetic, exec masks), and every SGPR spilled to a VGPR lane
+  // costs a v_readlane per use and row.  Only the packed-FMA taps must be SGPR pairs.
+#define B4_IN_VGPR(x) asm volatile("" : "+v"(x))
+  float ind_k1 = a.ind_k1, ind_k0 = a.ind_k0;
+  float qc = a.q[c];
+  float xw0 = a.xw[0 * 4 + c], xw1 = a.xw[1 * 4 + c], xw2 = a.xw[2 * 4 + c], xw3 = a.xw[3 * 4 + c];
+  float m1c = a.m1[c];                             // 1 - sum_k xw[k][c] * eps^q_k: the "1 +" of the mask and the eps terms of safe_pow
+  float inv_dmax = a.inv_dmax;
+  B4_IN_VGPR(ind_k0); B4_IN_VGPR(xw1); B4_IN_VGPR(xw2); B4_IN_VGPR(xw3); B4_IN_VGPR(m1c); B4_IN_VGPR(inv_dmax);
+#undef B4_IN_VGPR
 
   // ---- expand, vertical half (lpyr_dec.py:229-232): a rolling window of three coarse rows (my-1, my, my+1, clamped)
   // in registers, my = row >> 1.  While the fine rows ascend inside the image (everywhere but the reflected rows at the
@@ -133,17 +139,20 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   // row shares its predecessor's window, an even row needs the next coarse row up.  Otherwise the whole window is reloaded.
   auto coarse_issue = [&](int q, auto odd, auto fast) {
     if constexpr (!decltype(fast)::value) {
-      const int my = min(refl(q, H), H - 1) >> 1;
-      cA = coarse_load(max(my - 1, 0));
-      cB = coarse_load(my);
-      cC = coarse_load(min(my + 1, Hc - 1));
+      // (an odd row inside the image shares its predecessor's window here too: the rolling loop that may follow finishes
+      // such a row without touching the window, so it must not be handed a raw, un-replicated reload)
+      if (!(decltype(odd)::value && q >= 1 && q <= H - 1)) {
+        const int my = min(refl(q, H), H - 1) >> 1;
+        cA = coarse_load(max(my - 1, 0));
+        cB = coarse_load(my);
+        cC = coarse_load(min(my + 1, Hc - 1));
+      }
     }
   };
   // move the window to the row requested last (same odd / fast as its coarse_issue) and write its vertically expanded row to s_ve[buf]
   auto coarse_finish = [&](int buf, auto odd, auto fast) {
     if constexpr (decltype(fast)::value) {
       if constexpr (!decltype(odd)::value) { cA = cB; cB = cC; cC = replicate(make_float4(cN.x, cN.y, cN.z, cN.w)); }
-      else { cB = replicate(cB); cC = replicate(cC); }   // idempotent; the first rolling step finishes a row that was reloaded raw
     } else {
       cA = replicate(cA); cB = replicate(cB); cC = replicate(cC);
     }
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
 
   // horizontal half of the expand for this lane's 4 columns from 4 coarse values (lpyr_dec.py:234-237)
   auto expand4 = [&](const float2* row, float (&ex)[4]) {
-    // coarse cb+2j-1 .. cb+2j+2 live at elements 2j+3 .. 2j+6: three aligned ds_read_b64 (conflict-free)
+    // coarse cb+2j-1 .. cb+2j+2 live at elements 2j+3 .. 2j+6
     const float2 p0 = row[j + 1];
     const float2 p1 = row[j + 2];
     const float2 p2 = row[j + 3];
@@ -204,10 +213,15 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   v32f winA = 0.0f, winB = 0.0f;   // columns (0,1) and (2,3) interleaved: element 2s+i = slot s of column i
   // horizontal taps carry the mask gain 10^mask_c (the blur is linear; a.blur_h is pre-scaled on the host so that the
   // taps stay in SGPRs): Mq needs no extra multiply
-  v2f be[6], bo[6];
-#pragma unroll
-  for (int m = 0; m < 6; ++m) { be[m] = v2f{a.blur_h[2 * m], a.blur_h[2 * m + 1]}; bo[m] = v2f{a.blur_h[2 * m + 1], a.blur_h[2 * m + 2]}; }
-  const float b0 = a.blur_h[0], b12 = a.blur_h[12];
+  // The taps are symmetric (b[k] = b[12-k]), so the twelve tap pairs of the two alignments are seven SGPR pairs and
+  // their lane swaps (op_sel on the packed FMA): 14 SGPRs instead of 25.
+  const v2f E0 = {a.blur_h[0], a.blur_h[1]}, E1 = {a.blur_h[2], a.blur_h[3]}, E2 = {a.blur_h[4], a.blur_h[5]}, E3 = {a.blur_h[6], a.blur_h[5]};
+  const v2f O0 = {a.blur_h[1], a.blur_h[2]}, O1 = {a.blur_h[3], a.blur_h[4]}, O2 = {a.blur_h[5], a.blur_h[6]};
+#define B4_SWAP(p) __builtin_shufflevector(p, p, 1, 0)
+  const v2f be[6] = {E0, E1, E2, E3, B4_SWAP(O1), B4_SWAP(O0)};
+  const v2f bo[6] = {O0, O1, O2, B4_SWAP(E2), B4_SWAP(E1), B4_SWAP(E0)};
+#undef B4_SWAP
+  const float b0 = a.blur_h[0], b12 = a.blur_h[0];
   float wr[B4_BW];     // wr[s] = weight of slot s for the NEXT row to be written into slot 0
 #pragma unroll
   for (int k = 0; k < B4_BW; ++k) wr[k] = a.blur[(k + B4_BW - 1) % B4_BW];
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     coarse_issue(r0, std::false_type{}, std::false_type{});        // r0 is even
     stream_issue(r0 - 2, std::false_type{});                       // g rows of row r0
     coarse_finish(0, std::false_type{}, std::false_type{});
-    coarse_issue(r0 + 1, std::true_type{}, std::false_type{});     // (a reload is valid for any row)
+    coarse_issue(r0 + 1, std::true_type{}, std::false_type{});
     stream_issue(r0 - 1, std::true_type{});                        // g rows of row r0+1, coarse row for the move of row r0+2
   }
   __syncthreads();

@@ -62,7 +62,12 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   // s_ve is a ring of two rows (row parity): row r+1 is written during phase 1 of row r, so that phase 2 can derive
   // the per-column luminance terms of row r+1 (s_lum) from its luminance planes (0, 1).
   __shared__ __attribute__((aligned(16))) float2 s_ve[2][NP][B4_VE / 2];   // float2 rows: guaranteed 8-byte aligned ds_read_b64
-  __shared__ __attribute__((aligned(16))) float s_lum[4][256];             // 1/L_T, 1/L_R, CSF-LUT fraction, LUT byte offset
+  // CSF sensitivity: published per channel and column by the luminance stage (s_S), except in the heat-map variant, whose
+  // LDS budget (3 blocks per CU: 53 KB) has no room for it: there the luminance stage publishes the LUT position
+  // (fraction, byte offset) and every channel wave does its own lerp + exp2
+  constexpr bool S_SHARED = !HEAT;
+  __shared__ __attribute__((aligned(16))) float s_lum[S_SHARED ? 2 : 4][256];   // 1/L_T, 1/L_R [, LUT fraction, LUT byte offset]
+  __shared__ __attribute__((aligned(16))) float s_S[S_SHARED ? NCH : 1][S_SHARED ? 256 : 4];
   __shared__ __attribute__((aligned(16))) float s_m[NCH][256];
   __shared__ __attribute__((aligned(16))) float s_q[NCH][256];
   __shared__ __attribute__((aligned(16))) float s_d[B4_R + 1][NCH][B4_SW];   // lane-private ring of |T'-R'| + eps: interior columns only
@@ -72,7 +77,14 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   const int t = threadIdx.x;
   const int c = __builtin_amdgcn_readfirstlane(t >> 6);   // channel = wave: a scalar, so per-channel constants live in SGPRs
   const int j = t & 63;
-  const int strip = blockIdx.x, seg = blockIdx.y, item = blockIdx.z;
+  // XCD-aware block order.  Workgroups are dealt to the 8 XCDs round-robin by launch index, and each XCD has its own L2.
+  // Work unit w = (item, seg, strip) with the strip fastest: launch index b is mapped to w = (b % 8) * per_xcd + b / 8, so the
+  // blocks resident on one XCD at any time are CONSECUTIVE work units, i.e. neighbouring strips of the same rows, whose
+  // overlapping halo columns and shared 128-byte lines are then fetched from HBM once instead of once per strip.
+  const int per_xcd = a.per_xcd;
+  const int wu = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (wu >= a.n_strip * a.n_seg * a.items) return;      // (block-uniform: the grid is rounded up to 8 * per_xcd)
+  const int strip = wu % a.n_strip, seg = (wu / a.n_strip) % a.n_seg, item = wu / (a.n_strip * a.n_seg);
   const int H = a.H, W = a.W, Hc = a.Hc, Wc = a.Wc;
   const int x0 = strip * B4_SW;
   const int fc0 = x0 - B4_HALO + 4 * j;             // first of this lane's 4 columns
@@ -182,9 +194,8 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   };
 
   // Per-column luminance terms of one row, shared by all channels (lpyr_dec.py:394,:408; interp.py:93): every
-  // thread expands the luminance planes for ONE column (blocks of 64*NCH columns) and publishes 1/L_T, 1/L_R,
-  // the LUT interpolation fraction and the LUT byte offset, so each channel wave spends 1 SFU op per pixel
-  // on the CSF instead of 4.  Element 4+i of an s_ve row is coarse column cb+i; fine column col -> 4+(col>>1).
+  // thread expands the luminance planes for ONE column (blocks of 64*NCH columns) and publishes 1/L_T, 1/L_R
+  // and the sensitivity of every channel (LUT lerp + exp2), so the log / reciprocal work is done once per pixel.  Element 4+i of an s_ve row is coarse column cb+i; fine column col -> 4+(col>>1).
   const bool lodd = t & 1;                           // 64*NCH is even: a thread's columns keep their parity
   const float lwa = lodd ? 0.0f : e0, lwb = lodd ? eo : e1, lwc = lodd ? eo : e0;
   auto lum_prep = [&](int buf) {
@@ -198,10 +209,19 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
       float ind = fast_log2(Lr) * ind_k1 - ind_k0;
       ind = __builtin_amdgcn_fmed3f(ind, 0.0f, (float)(CVVDP_CSF_NODES - 1));  // clamp (interp.py:93)
       const int i0 = (int)ind;
+      const float fr = __builtin_amdgcn_fractf(ind);                           // ind >= 0: ind - floor(ind)
       s_lum[0][col] = fast_rcp(Lt);
       s_lum[1][col] = fast_rcp(Lr);
-      s_lum[2][col] = __builtin_amdgcn_fractf(ind);                            // ind >= 0: ind - floor(ind)
-      s_lum[3][col] = __int_as_float(i0 * 8);                                  // byte offset into a float2 LUT row
+      if constexpr (S_SHARED) {
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc) {                                     // csf.py:49, cvvdp_metric.py:709,:836
+          const float2 ln = s_lut[cc][i0];
+          s_S[cc][col] = fast_exp2(ln.x + ln.y * fr);
+        }
+      } else {
+        s_lum[2][col] = fr;
+        s_lum[3][col] = __int_as_float(i0 * 8);                                // byte offset into a float2 LUT row
+      }
     }
   };
 
@@ -267,7 +287,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     }
   };
 
-  // ---- STREAM LOADS.  The g rows (two planes, nontemporal: read once) and the coarse window's next row are requested a
+  // ---- STREAM LOADS.  The g rows (two planes) and the coarse window's next row are requested a
   // whole row (two phases) before they are used and must stay in flight across a barrier and the other row's loads.
   // hipcc's wait-count insertion drains the queue (vmcnt(0)) at the first use after a loop back edge, which halves the
   // bytes in flight and leaves the kernel waiting for HBM (57 % of the wave cycles parked, measured).  So these loads
@@ -283,8 +303,13 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   // tools/check_band4_isa.py checks the generated code for that).  Out-of-image halo lanes read a clamped, valid address.
   const uint32_t goff = (uint32_t)min(max(fc0, 0), W - 4) * 4u;
   v4f p0T = 0.0f, p0R = 0.0f, p1T = 0.0f, p1R = 0.0f;       // g rows of the even / odd row in flight
+// (no nontemporal hint: with the XCD-aware block order the halo columns and edge lines a strip shares with its neighbours
+// are L2 hits, 11.2 instead of 12.0 MB-K of FETCH_SIZE per 4K x 64 launch)
+#ifndef B4_NT_STR
+#define B4_NT_STR ""
+#endif
 #define B4_G_LOAD(dst, plane, row) \
-  asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "+v"(dst) : "v"(goff), "s"((plane) + (int64_t)(row) * W))
+  asm volatile("global_load_dwordx4 %0, %1, %2" B4_NT_STR : "+v"(dst) : "v"(goff), "s"((plane) + (int64_t)(row) * W))
 #define B4_C_LOAD(dst, row) \
   asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(gcl + (int64_t)(row) * Wc))
 #define B4_WAIT_EVEN() asm volatile("s_waitcnt vmcnt(3)" : "+v"(p0T), "+v"(p0R))
@@ -345,14 +370,23 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
       float exT[4], exR[4];
       expand4(s_ve[ODD][2 * c], exT);
       expand4(s_ve[ODD][2 * c + 1], exR);
-      const f4 rLt = lds_read4(&s_lum[0][4 * j]), rLr = lds_read4(&s_lum[1][4 * j]), fr = lds_read4(&s_lum[2][4 * j]);
-      const f4 lo = lds_read4(&s_lum[3][4 * j]);
+      const f4 rLt = lds_read4(&s_lum[0][4 * j]), rLr = lds_read4(&s_lum[1][4 * j]);
+      f4 Sv;
+      if constexpr (S_SHARED) {
+        Sv = lds_read4(&s_S[c][4 * j]);
+      } else {
+        const f4 fr = lds_read4(&s_lum[2][4 * j]), lo = lds_read4(&s_lum[3][4 * j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float2 ln = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(&s_lut[c][0]) + __float_as_int(lo.v[i]));
+          Sv.v[i] = fast_exp2(ln.x + ln.y * fr.v[i]);                          // csf.py:49, cvvdp_metric.py:709,:836
+        }
+      }
       const float gt[4] = {pT.x, pT.y, pT.z, pT.w}, gr[4] = {pR.x, pR.y, pR.z, pR.w};
       float m[4], d[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float2 ln = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(&s_lut[c][0]) + __float_as_int(lo.v[i]));
-        const float S = fast_exp2(ln.x + ln.y * fr.v[i]);                        // csf.py:49, cvvdp_metric.py:709,:836
+        const float S = Sv.v[i];
         const float ct = fminf((gt[i] - exT[i]) * rLt.v[i], 1000.0f);            // lpyr_dec.py:402 (band gain :66 is in S)
         const float cr = fminf((gr[i] - exR[i]) * rLr.v[i], 1000.0f);
         m[i] = fminf(fabsf(ct), fabsf(cr)) * S;                                  // min(|T'|,|R'|), T' = ct*S (cvvdp_metric.py:845)
@@ -398,11 +432,10 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
         h[2] = (s2.x + b12 * xp[8].x) + s2.y;
         h[3] = (s3.x + b0 * xp[2].y) + s3.y;
       }
-      float v[4];
       winA[2 * slot] = h[0]; winA[2 * slot + 1] = h[1]; winB[2 * slot] = h[2]; winB[2 * slot + 1] = h[3];
       // weight of slot s when the newest row sits in `slot`: window position j = (s - slot - 1) mod 13 -> wr[]
       // is kept rotated so that wr[s] is exactly that weight; columns (0,1) and (2,3) share one packed FMA
-      {
+      if (yc >= ys) {                                     // (the first twelve rows of a segment only fill the window)
         v2f va = 0.0f, vb = 0.0f;
 #pragma unroll
         for (int sdx = 0; sdx < B4_BW; ++sdx) {
@@ -410,9 +443,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
           const v2f ww = {wr[sdx], wr[sdx]};
           va += ww * wa; vb += ww * wb;
         }
-        v[0] = va.x; v[1] = va.y; v[2] = vb.x; v[3] = vb.y;
-      }
-      if (yc >= ys) {
+        const float v[4] = {va.x, va.y, vb.x, vb.y};
         float Mq[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) Mq[i] = fast_pow(v[i] + kEps, qc);   // cvvdp_metric.py:849; "- eps^q" is inside m1c
@@ -473,8 +504,10 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
 #undef B4_WAIT_ODD
 #undef B4_DRAIN
 
-void launch_band4(const BandArgs& a, hipStream_t s) {
-  dim3 grid(a.n_strip, a.n_seg, a.items);
+void launch_band4(const BandArgs& a0, hipStream_t s) {
+  BandArgs a = a0;
+  a.per_xcd = (a.n_strip * a.n_seg * a.items + 7) / 8;
+  dim3 grid(8 * a.per_xcd);
   if (a.dchr) {
     if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_band4<3, true>), grid, dim3(192), 0, s, a);

@@ -318,7 +318,10 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
       // video: the nominal block is 64 frames, or the whole clip if that is shorter (total_frames is the same for every
       // block and shard of a clip); an image launch holds exactly `batch` items
       const int clip_frames = c.total_frames > 0 ? c.total_frames : 64;
-      const int nominal = c.is_video ? std::min(64, clip_frames) : 1, target = 768, max_rows = c.is_video ? 384 : 256;
+      static const int target_env = getenv("CVVDP_SEG_TARGET") ? atoi(getenv("CVVDP_SEG_TARGET")) : 0;       // tuning knobs (development)
+      static const int rows_env = getenv("CVVDP_SEG_ROWS") ? atoi(getenv("CVVDP_SEG_ROWS")) : 0;
+      const int nominal = c.is_video ? std::min(64, clip_frames) : 1, target = target_env > 0 ? target_env : 768;
+      const int max_rows = rows_env > 0 ? rows_env : (c.is_video ? 384 : 256);
       const int per_seg = lv.n_strip * nominal * c.batch;
       const int want = (target + per_seg - 1) / per_seg;
       const int lo = (H + max_rows - 1) / max_rows, hi = std::max(lo, (H + 15) / 16);

@@ -109,6 +109,7 @@ struct BandArgs {
   int32_t H, W, Hc, Wc;
   int32_t items, items_cap, nch;
   int32_t seg_h, n_seg, n_strip;
+  int32_t per_xcd;   // k_band4: work units per XCD (set by launch_band4)
   float band_mul;
   float lut[4 * CVVDP_CSF_NODES];
   float logL_first, logL_last;

@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the ColorVideoVDP hot path on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload 4k64|fhd64|4k256] [--dtype f32|u8|yuv420p8|yuv420p10]
+    python bench.py [--gpus N --steps K --warmup W] [--workload 4k64|fhd64|4k256|4k1024|8k256pq] [--dtype f32|u8|yuv420p8|yuv420p10]
+                    [--heatmap none|raw|threshold|supra-threshold] [--distogram] [--gen cpu|gpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one full predict() of the workload clip pair (display model -> DKL -> temporal FIR ->
 contrast pyramid -> CSF -> masking -> pooling -> JOD) with the test/reference clips already resident in
-HBM.  With N GPUs the clip is N times longer and sharded by frame range (each rank: its frames + a
-16-frame real halo, one RCCL all-gather of Q_per_ch, pooling on every rank): weak scaling.
+HBM.  Clips are sharded over the N GPUs by frame range (each rank: its frames + a 16-frame real halo, one RCCL
+all-gather of Q_per_ch, pooling on every rank):
+  * 4k64 (the BASELINE.json metric clip), fhd64, 4k256: frames PER GPU -- the clip grows with N (weak scaling);
+  * 4k1024 (configs[3]) and 8k256pq (configs[4], PQ, supra-threshold heat map streamed off the GPU + distogram): frames in
+    TOTAL -- every rank scores 1/N of the clip (strong scaling).
 
-Prints ONE JSON line (rank 0).  value = Mpixel/s of the whole job = W*H*frames_scored_by_all_ranks*K / t.
+Prints ONE JSON line (rank 0).  value = Mpixel/s of the whole job = W*H*frames_scored_by_all_ranks*K / t.  With one GPU
+and a clip the real reference was run on (tests/golden/bench_*.npz, oracle/make_goldens_bench.py) the frames are made with
+the CPU generator the fixture was made with, and the line carries jod_delta_vs_reference of the very clip it times.
 """
 import argparse
 import json
@@ -24,14 +30,20 @@ import numpy as np
 import torch
 
 WORKLOADS = {
-    # name: (W, H, frames per GPU, fps, display)
-    "4k64": (3840, 2160, 64, 60, "standard_4k"),      # BASELINE.json metric: "4K@60fps 64-frame clip"
-    "fhd64": (1920, 1080, 64, 60, "standard_fhd"),    # configs[1]
-    "4k256": (3840, 2160, 256, 60, "standard_4k"),    # configs[2]
+    # name: (W, H, frames, fps, display, frames are per GPU?, default dtype, default heat map)
+    "4k64": (3840, 2160, 64, 60, "standard_4k", True, "f32", "none"),       # BASELINE.json metric: "4K@60fps 64-frame clip"
+    "fhd64": (1920, 1080, 64, 60, "standard_fhd", True, "f32", "none"),     # configs[1]
+    "4k256": (3840, 2160, 256, 60, "standard_4k", True, "f32", "none"),     # configs[2]
+    "4k1024": (3840, 2160, 1024, 60, "standard_4k", False, "u8", "none"),   # configs[3]: 1024 frames over the GPUs of the node
+    "8k256pq": (7680, 4320, 256, 60, "standard_hdr_pq", False, "u8", "supra-threshold"),   # configs[4]: + heat map + distogram
 }
+GOLDEN = {("4k64", "f32"): "bench_4k64_f32", ("fhd64", "f32"): "bench_fhd64_f32", ("4k256", "u8"): "bench_4k256_u8"}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
-PATH_BYTES_PER_PIXEL = {"f32": 211.0, "u8": 193.0,   # SURVEY.md 8(d) whole-path algorithmic bytes
-                        "yuv420p8": 190.0, "yuv420p10": 193.0}   # same model with 3 / 6 input bytes per pixel pair
+# whole-path algorithmic bytes per pixel of the test clip.  "survey": SURVEY.md 8(d)'s model, which includes a DKL ring
+# (24 B written + 24 B read) that this design does not have; "build": what this build's kernels have to move --
+# FIR 24 in + 32 out, reduce 32*4/3 in + 32/3 out, band 32*4/3 + 32/3 in
+PATH_BYTES_PER_PIXEL = {"f32": 211.0, "u8": 193.0, "yuv420p8": 190.0, "yuv420p10": 193.0}
+BUILD_BYTES_PER_PIXEL = {"f32": 24 + 32 + 53.3 + 53.3, "u8": 6 + 32 + 53.3 + 53.3, "yuv420p8": 3 + 32 + 53.3 + 53.3, "yuv420p10": 6 + 32 + 53.3 + 53.3}
 BAND0_BYTES_PER_PIXEL = 40.0   # level-0 band kernel: reads g0 (8 planes x 4 B) + g1 (8 x 4 / 4)
 
 
@@ -59,16 +71,27 @@ def synth_frame(f, H, W, device, seed_ref=1234, seed_noise=5678):
 
 
 class ResidentClip:
-    """video source whose frames [lo, hi) live in HBM; implements the raw-block fast path."""
+    """video source whose frames [lo, hi) live in HBM; implements the raw-block fast path.  gen="cpu": the frames are made
+    with the CPU generator (the one the reference fixtures were made with) and uploaded; "gpu": made on the device (a
+    different random stream, much faster for long clips).  pq_range: map the codes into [0.10, 0.75] (about 0.3 .. 1000
+    cd/m^2 on a PQ display)."""
 
-    def __init__(self, n_total, lo, hi, H, W, fps, dtype, device):
+    def __init__(self, n_total, lo, hi, H, W, fps, dtype, device, gen="gpu", pq_range=False):
         self.n_total, self.lo, self.hi, self.H, self.W, self.fps = n_total, lo, hi, H, W, fps
         tdt = torch.float32 if dtype == "f32" else torch.uint8
         self.code = 3 if dtype == "f32" else 0
+        self.device_resident = True
         self.test = torch.empty((1, 3, hi - lo, H, W), dtype=tdt, device=device)
         self.ref = torch.empty((1, 3, hi - lo, H, W), dtype=tdt, device=device)
+        self.checksum_test = self.checksum_ref = 0
         for f in range(lo, hi):
-            t, r = synth_frame(f, H, W, device)
+            t, r = synth_frame(f, H, W, "cpu" if gen == "cpu" else device)
+            if gen == "cpu":
+                self.checksum_test += int(t.to(torch.int64).sum())
+                self.checksum_ref += int(r.to(torch.int64).sum())
+                t, r = t.to(device), r.to(device)
+            if pq_range:
+                t, r = ((x.float() * 0.65 + 0.10 * 255).round().to(torch.uint8) for x in (t, r))
             if dtype == "f32":
                 t, r = t.float() / 255, r.float() / 255
             self.test[0, :, f - lo] = t
@@ -150,7 +173,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="4k64", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="f32", choices=["f32", "u8", "yuv420p8", "yuv420p10"])
+    ap.add_argument("--dtype", default=None, choices=["f32", "u8", "yuv420p8", "yuv420p10"], help="input sample format (default: the workload's)")
+    ap.add_argument("--heatmap", default=None, choices=["none", "raw", "threshold", "supra-threshold"], help="default: the workload's")
+    ap.add_argument("--distogram", action="store_true", help="also write the distogram of the last step (default for 8k256pq)")
+    ap.add_argument("--gen", default=None, choices=["cpu", "gpu"], help="frame generator (default: cpu when a reference fixture exists for the clip)")
+    ap.add_argument("--frames", type=int, default=None, help="override the workload's frame count (per GPU or total)")
     ap.add_argument("--block-frames", type=int, default=None)
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
@@ -176,22 +203,36 @@ def main():
             torch.distributed.init_process_group(backend)
 
     import colorvideovdp_amd as cv
+    from colorvideovdp_amd.heatmap_writers import HeatmapFrameMeans
     from colorvideovdp_amd.sharding import plan_frame_shard
-    W, H, per_gpu, fps, display = WORKLOADS[args.workload]
-    n_total = per_gpu * world
+    W, H, frames, fps, display, per_gpu_frames, wl_dtype, wl_heat = WORKLOADS[args.workload]
+    frames = args.frames or frames
+    dtype = args.dtype or wl_dtype
+    heat = args.heatmap or wl_heat
+    heat = None if heat == "none" else heat
+    distogram = args.distogram or args.workload == "8k256pq"
+    n_total = frames * world if per_gpu_frames else frames
+    scaling = "weak" if per_gpu_frames else "strong"
     first, count = plan_frame_shard(n_total, rank, world)
-    m = cv.cvvdp(display_name=display, device=device, block_frames=args.block_frames)
+    m = cv.cvvdp(display_name=display, device=device, block_frames=args.block_frames, heatmap=heat)
     fl = int(np.ceil(0.250 * fps / 2) * 2) + 1   # cvvdp_metric.py:1059
     lo = max(0, first - (fl - 1))
-    if args.dtype.startswith("yuv"):
-        clip = ResidentYuvClip(n_total, lo, first + count, H, W, fps, 8 if args.dtype.endswith("p8") else 10, device)
+    golden = None
+    if world == 1 and args.frames is None and (args.workload, dtype) in GOLDEN:
+        gpath = os.path.join(ROOT, "tests", "golden", GOLDEN[(args.workload, dtype)] + ".npz")
+        if os.path.isfile(gpath):
+            golden = np.load(gpath, allow_pickle=False)
+    gen = args.gen or ("cpu" if golden is not None else "gpu")
+    if dtype.startswith("yuv"):
+        clip = ResidentYuvClip(n_total, lo, first + count, H, W, fps, 8 if dtype.endswith("p8") else 10, device)
     else:
-        clip = ResidentClip(n_total, lo, first + count, H, W, fps, args.dtype, device)
+        clip = ResidentClip(n_total, lo, first + count, H, W, fps, dtype, device, gen=gen, pq_range=args.workload == "8k256pq")
     if world > 1:
         m.set_frame_sharding("world")
+    sink = HeatmapFrameMeans() if heat is not None else None      # the heat map leaves the GPU block by block (bounded host memory)
 
     def step():
-        return m.predict_video_source(clip)
+        return m.predict_video_source(clip, heatmap_sink=sink) if sink is not None else m.predict_video_source(clip)
 
     for _ in range(args.warmup):
         jod, stats = step()
@@ -220,43 +261,76 @@ def main():
         return
     pixels = W * H * n_total * args.steps
     mpix = pixels / dt / 1e6
+    what = f"{W}x{H} {fps}fps, {display}, {dtype} input resident in HBM"
+    if world > 1:
+        what += (f", {frames}-frame clip pair per GPU ({n_total} frames total)" if per_gpu_frames else f", {n_total}-frame clip pair over {world} GPUs") \
+                + ", frame-range shards + 16-frame halo, one all-gather of Q_per_ch"
+    else:
+        what += f", {n_total}-frame clip pair"
+    if heat is not None:
+        what += f", {heat} heat map streamed to the host in blocks"
     out = {
         "metric": "Mpixels/s", "value": round(mpix, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{W}x{H} {fps}fps {per_gpu}-frame clip pair per GPU ({n_total} frames total), {display}, "
-                               f"{args.dtype} input resident in HBM, frame-range shards + 16-frame halo" if world > 1 else
-                               f"{W}x{H} {fps}fps {per_gpu}-frame clip pair, {display}, {args.dtype} input resident in HBM",
-                   "frames_per_gpu": per_gpu, "input_dtype": args.dtype, "block_frames": getattr(m, "last_block_frames", None)},
+        "config": {"workload": what, "name": args.workload, "frames_total": n_total, "frames_this_gpu": count, "input_dtype": dtype,
+                   "heatmap": heat or "none", "frame_generator": gen, "block_frames": getattr(m, "last_block_frames", None)},
         "jod": round(float(jod), 5),
-        "path_roofline": {"bytes_per_pixel": PATH_BYTES_PER_PIXEL[args.dtype],
-                          "achieved_GBs": round(PATH_BYTES_PER_PIXEL[args.dtype] * pixels / dt / 1e9 / world, 1),
-                          "frac_of_8TBs_per_gpu": round(PATH_BYTES_PER_PIXEL[args.dtype] * pixels / dt / 1e9 / world / HBM_PEAK_GBS, 4)},
+    }
+    if golden is not None and gen == "cpu":
+        if (clip.checksum_test, clip.checksum_ref) == (int(golden["checksum_test"]), int(golden["checksum_ref"])):
+            q, qr = stats["Q_per_ch"].astype(np.float64), golden["Q_per_ch"].astype(np.float64)
+            out["jod_reference"] = round(float(golden["jod"]), 5)
+            out["jod_delta_vs_reference"] = float(abs(float(jod) - float(golden["jod"])))
+            out["q_per_ch_max_rel_err_vs_reference"] = float(np.max(np.abs(q - qr) / (np.abs(qr) + 1e-6)))
+            out["reference_fixture"] = f"tests/golden/{GOLDEN[(args.workload, dtype)]}.npz (the real reference on this very clip, oracle/make_goldens_bench.py)"
+        else:
+            out["jod_delta_vs_reference"] = None      # this torch build's CPU generator does not reproduce the fixture's frames
+    surv, build = PATH_BYTES_PER_PIXEL[dtype], BUILD_BYTES_PER_PIXEL[dtype]
+    out["path_roofline"] = {
+        "survey_model": {"bytes_per_pixel": surv, "achieved_GBs": round(surv * pixels / dt / 1e9 / world, 1),
+                         "frac_of_8TBs_per_gpu": round(surv * pixels / dt / 1e9 / world / HBM_PEAK_GBS, 4),
+                         "note": "SURVEY.md 8(d): includes a 48 B/pixel DKL ring this design does not have"},
+        "build_algorithmic": {"bytes_per_pixel": round(build, 1), "achieved_GBs": round(build * pixels / dt / 1e9 / world, 1),
+                              "frac_of_8TBs_per_gpu": round(build * pixels / dt / 1e9 / world / HBM_PEAK_GBS, 4)},
     }
     if prof is not None:
         ms, n = prof["band_level0"]
         frames_per_launch = count * args.steps / max(n, 1)
         avg_ms = ms / max(n, 1)
         ach = BAND0_BYTES_PER_PIXEL * W * H * frames_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_band0.json")
+        traffic, ktraffic = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.isfile(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj.get("workload") == args.workload and tj.get("dtype") == args.dtype:
-                traffic = tj.get("hbm_bytes_per_launch")
+            if tj.get("workload") == args.workload and tj.get("dtype") == dtype:
+                ktraffic = tj.get("kernels")
+                traffic = (ktraffic or {}).get("band_level0", {}).get("hbm_bytes_per_launch")
         out["roofline"] = {"bound": "hbm", "kernel": "k_band4<4> level 0 (fused expand/contrast/CSF/masking/blur/pooling)",
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": n,
                            "algorithmic_bytes_per_launch": BAND0_BYTES_PER_PIXEL * W * H * frames_per_launch}
+        if ktraffic:
+            out["kernel_traffic"] = ktraffic     # counter bytes vs algorithmic bytes of every dominant kernel (profiles/traffic.json)
         tot = sum(v[0] for v in prof.values())
         out["kernel_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in prof.items()}
         out["kernel_ms_per_step"]["sum"] = round(tot / args.steps, 3)
+    if sink is not None:
+        out["heatmap_frames_streamed_per_step"] = sink.frames_seen // (args.steps + args.warmup)
+    if distogram:
+        try:
+            path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"bench_distogram_{args.workload}.png")
+            m.export_distogram(stats, path, jod_max=10)
+            out["distogram_bytes"] = os.path.getsize(path)
+        except Exception as e:   # matplotlib is optional on the box
+            out["distogram_bytes"] = None
+            out["distogram_error"] = repr(e)
     if args.cpu_frames > 0 and world == 1:
         cb, ojod, t, r = cpu_baseline(W, H, fps, display, args.cpu_frames)
         out["cpu_baseline"] = cb
         hjod, _ = cv.cvvdp(display_name=display, device=device).predict(t, r, dim_order="BCFHW", frames_per_second=fps)
-        out["jod_delta_vs_oracle"] = float(abs(float(hjod) - ojod))
+        out["jod_delta_vs_oracle_sample"] = float(abs(float(hjod) - ojod))
     print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

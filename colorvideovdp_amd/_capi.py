@@ -12,7 +12,7 @@ MAX_WINDOW = 256
 CSF_NODES = 32
 PROF_N = 6
 PROF_NAMES = ("photometry", "temporal_fir", "pyr_reduce", "band_level0", "band_rest", "heatmap")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 U8, U16, F16, F32, F32_DKL, YUV8, YUV16 = range(7)
 HEATMAP = {None: 0, "none": 0, "raw": 1, "threshold": 2, "supra-threshold": 3}
@@ -81,6 +81,8 @@ SYMBOLS = {
                                       C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p]),
     "cvvdp_process_block_yuv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(YuvFormat), C.c_int32, C.POINTER(C.c_int32),
                                           C.c_int32, C.c_int32, C.c_void_p]),
+    "cvvdp_process_block_filtered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                               C.c_int32, C.c_int32, C.c_void_p]),
     "cvvdp_process_image": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cvvdp_get_q_per_ch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvvdp_pool_jod": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -519,6 +519,30 @@ static int process_block_impl(cvvdp_handle* h, const void* t, const void* r, int
   return run_pyramid_and_bands(h, n_frames, q_frame_offset, s);
 }
 
+int cvvdp_process_block_filtered(cvvdp_handle* h, const void* t, const void* r, const int64_t st[5], const int64_t sr[5],
+                                 int32_t n_frames, int32_t q_frame_offset, void* stream) {
+  if (!h || !h->ws) return fail(h, CVVDP_E_STATE, "no workspace bound");
+  const cvvdp_clip& c = h->c;
+  if (!c.is_video) return fail(h, CVVDP_E_STATE, "configured for an image");
+  if (!t || !r || !st || !sr) return fail(h, CVVDP_E_ARG, "bad frame arguments");
+  if (n_frames < 1 || n_frames > c.block_frames) return fail(h, CVVDP_E_ARG, "n_frames out of range");
+  if (q_frame_offset < 0 || q_frame_offset + n_frames > c.n_frames) return fail(h, CVVDP_E_ARG, "frame offset out of range");
+  if (h->pipeline) return fail(h, CVVDP_E_UNSUPPORTED, "pre-filtered frames are not supported with CVVDP_PIPELINE");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  PutPlanesArgs a{};
+  a.src[0] = static_cast<const float*>(t); a.src[1] = static_cast<const float*>(r);
+  const int64_t* S[2] = {st, sr};
+  for (int k = 0; k < 2; ++k) { a.sb[k] = S[k][0]; a.sc[k] = S[k][1]; a.sf[k] = S[k][2]; a.sh[k] = S[k][3]; a.sw[k] = S[k][4]; }
+  a.H = c.height; a.W = c.width; a.batch = c.batch; a.n_frames = n_frames;
+  a.dst = gbase(h, 0, 0); a.o_plane = (int64_t)h->items_cap * h->lv[0].P;
+  {
+    ProfScope ps(h, CVVDP_PROF_FIR, s);
+    launch_put_planes(a, s);
+  }
+  if (int e = check_launch(h, "put planes")) return e;
+  return run_pyramid_and_bands(h, n_frames, q_frame_offset, s);
+}
+
 int cvvdp_process_image(cvvdp_handle* h, void* stream) {
   if (!h || !h->ws) return fail(h, CVVDP_E_STATE, "no workspace bound");
   if (h->c.is_video) return fail(h, CVVDP_E_STATE, "configured for video");

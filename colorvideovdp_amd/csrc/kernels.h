@@ -42,6 +42,14 @@ struct PhotoArgs {
   int32_t first_slot, n_slots;        // slot = (first_slot + f) % n_slots
 };
 void launch_photometry(const PhotoArgs& a, hipStream_t s);
+struct PutPlanesArgs {       // pre-filtered 4-channel frames -> the 8 level-0 planes (cvvdp_metric.py:470-488)
+  const float* src[2];      // test, ref: [B, 4, n, H, W] with element strides
+  int64_t sb[2], sc[2], sf[2], sh[2], sw[2];
+  int32_t H, W, batch, n_frames;
+  float* dst;               // level-0 planes [plane][item][P]
+  int64_t o_plane;          // items_cap * P
+};
+void launch_put_planes(const PutPlanesArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- temporal FIR (K1)
 constexpr int CVVDP_ROT_TAPS = 40;

@@ -72,4 +72,22 @@ void launch_photometry(const PhotoArgs& a, hipStream_t s) {
   }
 }
 
+// Pre-filtered sources (cvvdp_metric.py:470-488): channel c of the test frames is level-0 plane 2c, of the reference 2c+1.
+__global__ __launch_bounds__(256) void k_put_planes(PutPlanesArgs a) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int P = a.H * a.W;
+  if (pix >= P) return;
+  const int item = blockIdx.y, plane = blockIdx.z;      // item = f * batch + b
+  const int side = plane & 1, ch = plane >> 1;
+  const int f = item / a.batch, b = item - f * a.batch;
+  const int y = pix / a.W, x = pix - y * a.W;
+  a.dst[plane * a.o_plane + (int64_t)item * P + pix] =
+      a.src[side][b * a.sb[side] + ch * a.sc[side] + f * a.sf[side] + (int64_t)y * a.sh[side] + (int64_t)x * a.sw[side]];
+}
+
+void launch_put_planes(const PutPlanesArgs& a, hipStream_t s) {
+  dim3 grid((a.H * a.W + 255) / 256, a.n_frames * a.batch, 8);
+  hipLaunchKernelGGL(k_put_planes, grid, dim3(256), 0, s, a);
+}
+
 }  // namespace cvvdp

@@ -40,6 +40,33 @@ def _storage_is_unshared(t):
         return False
 
 
+class _SequentialFrames:
+    """Frames of a generic video_source (get_test_frame / get_reference_frame, already in the metric's colour space).  Every
+    frame is requested exactly ONCE and in increasing order -- the reference's file sources are strictly sequential
+    (video_source_file.py raises 'Random access not implemented' otherwise) -- and kept until no later block can need it:
+    the read-ahead frames of symmetric padding (cvvdp_metric.py:513-529, fb.ra_buf) are served from here."""
+
+    def __init__(self, vs, device, colorspace):
+        self.vs, self.device, self.colorspace = vs, device, colorspace
+        self.frames = {}
+
+    def block(self, a, b, reference_first=False):
+        for f in range(a, b):
+            if f not in self.frames:
+                if reference_first:   # cvvdp_metric.py:476-478: per-frame state (optical flow) is computed from the reference
+                    r = self.vs.get_reference_frame(f, device=self.device, colorspace=self.colorspace)
+                    t = self.vs.get_test_frame(f, device=self.device, colorspace=self.colorspace)
+                else:
+                    t = self.vs.get_test_frame(f, device=self.device, colorspace=self.colorspace)
+                    r = self.vs.get_reference_frame(f, device=self.device, colorspace=self.colorspace)
+                self.frames[f] = (t.to(self.device, torch.float32), r.to(self.device, torch.float32))
+        t = torch.cat([self.frames[f][0] for f in range(a, b)], dim=2).contiguous()
+        r = torch.cat([self.frames[f][1] for f in range(a, b)], dim=2).contiguous()
+        for f in [f for f in self.frames if f < a]:     # blocks move forward: nothing before this block's first frame comes back
+            del self.frames[f]
+        return t, r, _capi.F32_DKL
+
+
 class cvvdp(vq_metric):
     def __init__(self, display_name="standard_4k", display_photometry=None, display_geometry=None, config_paths=[],
                  heatmap=None, quiet=False, device=None, temp_padding="replicate", use_checkpoints=False, dump_channels=None,
@@ -63,6 +90,10 @@ class cvvdp(vq_metric):
             self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("colorvideovdp_amd runs on an MI355X only: device must be a CUDA/HIP device; there is no CPU path")
+        if self.device.index is None and torch.cuda.is_available():
+            # "cuda" and "cuda:0" compare unequal: pin the index once, so that workspace / input tensors are recognised as local
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self._cfg_version = 0          # bumped whenever parameters / display change: part of the clip-cache key
         self._handle = ctypes.c_void_p()
         self._ws = None
         self._shard = None
@@ -105,6 +136,8 @@ class cvvdp(vq_metric):
         self._make_handle()
 
     def _make_handle(self):
+        self._cfg_version = getattr(self, "_cfg_version", 0) + 1
+        self._clip_cache = None
         if not hasattr(self, "parameters") or not hasattr(self, "display_photometry"):
             return
         p, dm = self.parameters, self.display_photometry
@@ -173,41 +206,60 @@ class cvvdp(vq_metric):
         Q_jod, _ = self.predict(test_cont, reference_cont, dim_order=dim_order, frames_per_second=frames_per_second)
         return 10.0 - Q_jod
 
-    def predict_video_source(self, vid_source):
-        """cvvdp_metric.py:304-441."""
+    def predict_video_source(self, vid_source, heatmap_sink=None):
+        """cvvdp_metric.py:304-441.
+
+        heatmap_sink (extension): callable(first_frame, frames) that receives the heat map block by block
+        (`frames`: float16 CPU tensor [1, 1|3, n, H, W], valid only during the call) instead of `stats["heatmap"]`
+        holding the whole clip -- an 8K x 256-frame colour heat map is 51 GB.  See colorvideovdp_amd.heatmap_writers."""
         height, width, N_frames = vid_source.get_video_size()
         batch_sz = vid_source.get_batch_size()
         if batch_sz > 1 and self.do_heatmap:
             raise vq_exception("Heatmaps not supported when batches are used")
+        if heatmap_sink is not None and not self.do_heatmap:
+            raise vq_exception("heatmap_sink given, but the metric was created without a heat map")
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device available: colorvideovdp_amd has no CPU path")
         is_image = N_frames == 1
-        # a source that carries its own display photometry (video_source_dm, video_source.py:206-229) is measured
-        # with it; the metric's display geometry still sets the pixels per degree
+        # a RAW source (arrays, .yuv files) that carries its own display photometry (video_source_dm, video_source.py:206-229)
+        # is measured with it; the metric's display geometry still sets the pixels per degree.  Sources that hand out
+        # finished DKL frames have applied their display model themselves: theirs is never needed here (and may be an
+        # object of another package).
         src_dm = getattr(vid_source, "dm_photometry", None)
-        if src_dm is not None and src_dm is not self.display_photometry:
+        if src_dm is not None and src_dm is not self.display_photometry and self._is_raw_source(vid_source):
             prev = self.display_photometry
             self.display_photometry = src_dm
             self._make_handle()
             try:
-                return self._predict_video_source(vid_source, height, width, N_frames, is_image)
+                return self._predict_video_source(vid_source, height, width, N_frames, is_image, heatmap_sink)
             finally:
                 self.display_photometry = prev
                 self._make_handle()
-        return self._predict_video_source(vid_source, height, width, N_frames, is_image)
+        return self._predict_video_source(vid_source, height, width, N_frames, is_image, heatmap_sink)
 
-    def _predict_video_source(self, vid_source, height, width, N_frames, is_image):
+    @staticmethod
+    def _is_raw_source(vs):
+        return hasattr(vs, "get_raw_yuv_block") or hasattr(vs, "get_raw_block") or isinstance(vs, video_source_array)
+
+    def _predict_video_source(self, vid_source, height, width, N_frames, is_image, heatmap_sink=None):
         first, count = 0, N_frames
         group = None
+        sharded = False
         if self._shard is not None and not is_image and torch.distributed.is_available() and torch.distributed.is_initialized():
             group = None if self._shard == "world" else self._shard
             rank, world = torch.distributed.get_rank(group), torch.distributed.get_world_size(group)
             first, count = plan_frame_shard(N_frames, rank, world)
-        Q_local, heatmap, rho_band = self._score_range(vid_source, first, count)
-        if group is not None or (self._shard is not None and count != N_frames):
-            Q_per_ch = all_gather_frames(Q_local, N_frames, group)
+            sharded = True
+        if count > 0:
+            Q_local, heatmap, rho_band = self._score_range(vid_source, first, count, heatmap_sink)
         else:
-            Q_per_ch = Q_local
+            # more ranks than frames: this rank has nothing to score, but still joins the gather with an empty shard
+            pyr_height, freqs = hs.band_frequencies(width, height, self.pix_per_deg)
+            rho_band = freqs.copy()
+            rho_band[pyr_height] = 0.1
+            Q_local = torch.zeros((vid_source.get_batch_size(), 4, 0, pyr_height + 1), dtype=torch.float32, device=self.device)
+            heatmap = torch.empty((1, 1 if self.heatmap == "raw" else 3, 0, height, width), dtype=torch.float16) if self.do_heatmap else None
+        Q_per_ch = all_gather_frames(Q_local, N_frames, group) if sharded else Q_local
         Q_jod = self.do_pooling_and_jods(Q_per_ch)
         stats = {}
         stats["Q_per_ch"] = Q_per_ch.detach().cpu().numpy()
@@ -217,7 +269,8 @@ class cvvdp(vq_metric):
         stats["height"] = height
         stats["N_frames"] = N_frames
         if self.do_heatmap:
-            stats["heatmap"] = heatmap
+            if heatmap_sink is None:
+                stats["heatmap"] = heatmap
             if count != N_frames:
                 stats["heatmap_frame_range"] = (first, first + count)
         return (Q_jod.squeeze(), stats)
@@ -253,11 +306,13 @@ class cvvdp(vq_metric):
             t, r, code = vs.raw_arrays()
             return self._upload_frames(t, a, b), self._upload_frames(r, a, b), code
         # generic video_source: frames arrive one by one, already in DKL (cvvdp_metric.py:503-504)
-        ts = [vs.get_test_frame(f, device=self.device, colorspace="DKLd65") for f in range(a, b)]
-        rs = [vs.get_reference_frame(f, device=self.device, colorspace="DKLd65") for f in range(a, b)]
-        t = torch.cat(ts, dim=2).to(torch.float32).contiguous()
-        r = torch.cat(rs, dim=2).to(torch.float32).contiguous()
-        return t, r, _capi.F32_DKL
+        return self._seq_frames(vs).block(a, b)
+
+    def _seq_frames(self, vs, colorspace="DKLd65"):
+        sf = getattr(self, "_seq", None)
+        if sf is None or sf.vs is not vs or sf.colorspace != colorspace:
+            sf = self._seq = _SequentialFrames(vs, self.device, colorspace)
+        return sf
 
     def _upload_frames(self, x, a, b):
         """Frames [a,b) of a BCFHW tensor on the device.  Host tensors are copied plane by plane: x[b, c, a:b] is
@@ -292,7 +347,7 @@ class cvvdp(vq_metric):
             sr[0] = 0
         return (ctypes.c_int64 * 5)(*st), (ctypes.c_int64 * 5)(*sr)
 
-    def _score_range(self, vs, first, count):
+    def _score_range(self, vs, first, count, heatmap_sink=None):
         """Q_per_ch [B, C, count, bands] (device tensor) of frames [first, first+count)."""
         lib = _capi.lib()
         height, width, N_total = vs.get_video_size()
@@ -304,17 +359,25 @@ class cvvdp(vq_metric):
         rho_band = freqs.copy()
         rho_band[L - 1] = 0.1  # cvvdp_metric.py:685-686
         is_yuv = hasattr(vs, "get_raw_yuv_block")      # planar Y'CbCr file source: unpacked by the temporal kernel
+        generic = not self._is_raw_source(vs)           # frames arrive one by one, already in DKL
+        # sources with temporally pre-filtered channels bypass the sliding window + FIR (cvvdp_metric.py:470-488)
+        prefiltered = bool(getattr(vs, "is_temporally_filtered", False)) and not is_image
+        if prefiltered and not generic:
+            raise vq_exception("is_temporally_filtered is only meaningful for sources that deliver 'DKLd65_trans' frames")
+        self._seq = None
         if is_yuv:
             if is_image:
                 raise vq_exception("single-frame .yuv clips are not supported")
             C = 3
+        elif generic and not is_image:
+            C, code = 3, _capi.F32_DKL                  # no probe: a file source may only be read once, in order
         else:
             probe_t, probe_r, code = self._raw_block(vs, first, first + 1)
             C = probe_t.shape[1]
         # The clip description (temporal taps, CSF rows per band, block size) depends only on the geometry: repeated
         # calls on clips of the same shape reuse it, so the first kernel is not held back by ~0.4 ms of host set-up.
         key = (height, width, N_total, first, count, B, C, is_image, None if is_image else float(vs.get_frames_per_second()), self.heatmap,
-               bool(self.debug_dump), self.block_frames, self.gpu_mem, float(self.pix_per_deg), id(self.parameters), id(self.csf_table),
+               bool(self.debug_dump), self.block_frames, self.gpu_mem, float(self.pix_per_deg), self._cfg_version, prefiltered,
                self._host_resident(vs))
         cached = getattr(self, "_clip_cache", None)
         if cached is not None and cached[0] == key:
@@ -336,12 +399,12 @@ class cvvdp(vq_metric):
             if not is_image:
                 F = hs.temporal_filters(vs.get_frames_per_second(), self.parameters["beta_tf"], self.parameters["sigma_tf"])
                 self.F = F
-                fl = F.shape[1]
+                fl = 1 if prefiltered else F.shape[1]     # pre-filtered frames need no window
                 if fl > _capi.MAX_FILTER_LEN:
                     raise vq_exception(f"frame rates above {(_capi.MAX_FILTER_LEN - 1) * 4} fps are not supported")
                 self.filter_len = fl
                 taps = np.zeros((4, _capi.MAX_FILTER_LEN), dtype=f32)
-                taps[:, :fl] = F
+                taps[:, :fl] = F[:, :fl]
                 clip.taps[:] = taps.reshape(-1).tolist()
                 nb = self._pick_block_frames(height * width, B, count, fl, nch, self._host_resident(vs))
                 clip.filter_len, clip.block_frames = fl, nb
@@ -361,7 +424,17 @@ class cvvdp(vq_metric):
         heatmap = None
         hm_ch = 1 if self.heatmap == "raw" else 3
         copy_stream = None
-        if self.do_heatmap:
+        stage, pending_sink = None, []
+        if self.do_heatmap and heatmap_sink is not None:
+            # Streaming: two page-locked staging buffers of one block each; block k is handed to the sink while
+            # the kernels of block k+1 run.  Host memory is bounded by 2 blocks whatever the clip length.
+            nb_max = 1 if is_image else clip.block_frames
+            stage = getattr(self, "_hm_stage", None)
+            if stage is None or stage[0].numel() < hm_ch * nb_max * height * width:
+                stage = self._hm_stage = [torch.empty(hm_ch * nb_max * height * width, dtype=torch.float16, device="cpu", pin_memory=True) for _ in range(2)]
+            copy_stream = getattr(self, "_hm_stream", None) or torch.cuda.Stream(self.device)
+            self._hm_stream = copy_stream
+        elif self.do_heatmap:
             # The reference keeps the whole fp16 heat map on the CPU (cvvdp_metric.py:344).  Page-locked memory
             # + copies on a side stream keep the D2H traffic (6 B/pixel) off the compute stream.
             # Page-locking gigabytes costs more than filling them (~60 ms per GB), so the buffer of the previous call is
@@ -376,15 +449,33 @@ class cvvdp(vq_metric):
                 self._hm_base = None
                 try:
                     base = torch.empty(int(np.prod(shape)), dtype=torch.float16, device="cpu", pin_memory=True)   # every frame is written below
-                    copy_stream = torch.cuda.Stream(self.device)
+                    copy_stream = getattr(self, "_hm_stream", None) or torch.cuda.Stream(self.device)
                     self._hm_base, self._hm_stream = base, copy_stream
                     heatmap = base.view(shape)
                 except RuntimeError:
                     heatmap = torch.empty(shape, dtype=torch.float16, device="cpu")
 
+        def flush_sink(keep=0):
+            while len(pending_sink) > keep:
+                ev, frame0, view, _ = pending_sink.pop(0)
+                ev.synchronize()
+                heatmap_sink(frame0, view)
+
         def fetch_heatmap(ff, n):
             buf = torch.empty((hm_ch, n, height, width), dtype=torch.float16, device=self.device)
             _capi.check(self._handle, lib.cvvdp_get_heatmap(self._handle, n, buf.data_ptr(), stream), "cvvdp_get_heatmap")
+            if stage is not None:
+                flush_sink(keep=1)                         # the buffer about to be overwritten has been consumed
+                dst = stage[1] if (pending_sink and pending_sink[0][3] == 0) else stage[0]
+                view = dst[:hm_ch * n * height * width].view(1, hm_ch, n, height, width)
+                copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(copy_stream):
+                    view[0].copy_(buf, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                buf.record_stream(copy_stream)
+                pending_sink.append((ev, first + ff, view, 0 if dst is stage[0] else 1))
+                return
             # one copy per colour plane: heatmap[0, ch, ff:ff+n] is contiguous on the host, the [3, n, H, W] slice of a
             # longer clip is not (a strided D2H copy falls off the DMA path: 6x slower end to end)
             if copy_stream is None:
@@ -414,8 +505,21 @@ class cvvdp(vq_metric):
 
             if self.temp_padding not in ("replicate", "symmetric"):
                 raise RuntimeError(f'Unknown padding method "{self.temp_padding}"')
+            if prefiltered:
+                seq = self._seq_frames(vs, "DKLd65_trans")
+                for ff in range(first, first + count, nb):
+                    n = min(nb, first + count - ff)
+                    t, r, _ = seq.block(ff, ff + n, reference_first=True)
+                    if t.shape[1] != 4:
+                        raise vq_exception("a temporally filtered source must deliver 4-channel 'DKLd65_trans' frames")
+                    st, sr = self._strides(t, r)
+                    rc = lib.cvvdp_process_block_filtered(self._handle, t.data_ptr(), r.data_ptr(), st, sr, n, ff - first, stream)
+                    _capi.check(self._handle, rc, "cvvdp_process_block_filtered")
+                    if self.do_heatmap:
+                        fetch_heatmap(ff - first, n)
+                    del t, r
             blocks = []
-            for ff in range(first, first + count, nb):
+            for ff in (range(first, first + count, nb) if not prefiltered else ()):
                 n = min(nb, first + count - ff)
                 if ff == first or clip.raw_halo:
                     # first block of the clip / shard, and every block of a device-resident clip: the fl-1 window
@@ -485,7 +589,10 @@ class cvvdp(vq_metric):
                     pool.shutdown(wait=True)
         Q = torch.empty((B, nch, count, L), dtype=torch.float32, device=self.device)
         _capi.check(self._handle, lib.cvvdp_get_q_per_ch(self._handle, Q.data_ptr(), stream), "cvvdp_get_q_per_ch")
-        if copy_stream is not None:
+        self._seq = None
+        if stage is not None:
+            flush_sink()
+        elif copy_stream is not None:
             copy_stream.synchronize()   # the heat map is host data: it must be complete when predict() returns
         return Q, heatmap, rho_band
 
@@ -542,24 +649,26 @@ class cvvdp(vq_metric):
         with open(dest_fname, "w", encoding="utf-8") as f:
             json.dump(fmap, f, ensure_ascii=False, indent=4)
 
-    def export_distogram(self, stats, fname, jod_max=None, base_size=6):
-        """cvvdp_metric.py:1158-1218 (host only, needs matplotlib)."""
-        Q_per_ch = np.array(stats["Q_per_ch"], dtype=f32)
-        if Q_per_ch.shape[0] != 1:
+    def distogram_data(self, stats, jod_max=None):
+        """The numbers behind a distogram (cvvdp_metric.py:1160-1175): per channel, the JOD loss of every (frame, band)
+        cell, scaled by 1/jod_max.  Returns (panels [channels, bands, frames] in [0,1] with the baseband in the LAST row and
+        band 0 in the first -- the orientation imshow draws --, jod_max)."""
+        q = np.array(stats["Q_per_ch"], dtype=f32)
+        if q.shape[0] != 1:
             raise vq_exception("Exporting distograms in batch mode is not supported")
-        ch_no = Q_per_ch.shape[1]
-        is_image = Q_per_ch.shape[2] == 1
-        Q_per_ch[:, :, :, -1] *= self.baseband_weight[0:ch_no].reshape(-1, 1)
-        Q_per_ch *= self.get_ch_weights(ch_no) * ch_no
-        dmap = 10.0 - self.met2jod(Q_per_ch)
+        n_ch = q.shape[1]
+        q[..., -1] *= self.baseband_weight[:n_ch].reshape(-1, 1)     # the baseband has its own weight per channel
+        q *= self.get_ch_weights(n_ch) * n_ch
+        loss = 10.0 - self.met2jod(q)
         if jod_max is None:
-            jod_max = math.ceil(dmap.max())
-        dmap = dmap / jod_max
-        fps = stats["frames_per_second"]
-        frame_no = Q_per_ch.shape[2]
-        rho_band = stats["rho_band"]
-        band_labels = [f"{val:.2f}" for val in np.flip(rho_band)[::2]]
-        band_labels[0] = "BB"
+            jod_max = math.ceil(loss.max())
+        loss = (loss / jod_max).clip(0.0, 1.0)
+        return np.ascontiguousarray(loss[0].transpose(0, 2, 1)[:, ::-1, :]), jod_max
+
+    def export_distogram(self, stats, fname, jod_max=None, base_size=6):
+        """cvvdp_metric.py:1158-1218: one panel per channel, bands over time, written as an image (needs matplotlib).
+        Host-side reporting only: it draws what distogram_data() computes, with the reference's labels and layout."""
+        panels, jod_max = self.distogram_data(stats, jod_max)
         try:
             import matplotlib
             matplotlib.use("Agg")
@@ -568,29 +677,28 @@ class cvvdp(vq_metric):
             from matplotlib.colors import Normalize
         except ImportError:
             raise RuntimeError("matplotlib is missing. Please install it before exporting distograms.")
-        fig, axs = plt.subplots(nrows=ch_no, figsize=(base_size * frame_no / 60 + 1, base_size))
-        ch_labels = ["A-sust", "RG", "YV", "A-trans"]
+        n_ch, n_bands, n_frames = panels.shape
+        still = n_frames == 1
+        fps = stats["frames_per_second"]
+        labels = ["BB"] + [f"{rho:.2f}" for rho in np.flip(stats["rho_band"])[::2][1:]]     # every other band, coarsest first
         cmap = plt.colormaps["plasma"]
-        for kk in range(ch_no):
-            dmap_ch = np.flip(np.transpose(dmap[0, kk, :, :].clip(0.0, 1.0)), axis=0)
-            axs[kk].imshow(dmap_ch, cmap=cmap, aspect="auto")
-            axs[kk].set_ylabel(ch_labels[kk])
-            axs[kk].yaxis.set_major_locator(ticker.FixedLocator(range(0, len(band_labels) * 2, 2)))
-            axs[kk].yaxis.set_minor_locator(ticker.MultipleLocator(1.0))
-            axs[kk].set_yticklabels(band_labels)
-            if kk == (ch_no - 1) and not is_image:
-                axs[kk].xaxis.set_major_formatter(lambda x, pos: str(int(x / fps * 1000)))
-                axs[kk].set_xlabel("Time [ms]")
-                axs[kk].xaxis.set_minor_locator(ticker.MultipleLocator(1.0))
-            else:
-                axs[kk].set_xticks([])
-        if is_image:
-            plt.subplots_adjust(bottom=0.1, right=0.5, top=0.9)
-            cax = plt.axes([0.725, 0.1, 0.125, 0.8])
-        else:
-            plt.subplots_adjust(bottom=0.1, right=0.9, top=0.9)
-            cax = plt.axes([0.925, 0.1, 0.025, 0.8])
-        plt.colorbar(plt.cm.ScalarMappable(norm=Normalize(0, jod_max), cmap=cmap), cax=cax, cmap=cmap)
+        fig, axs = plt.subplots(nrows=n_ch, figsize=(base_size * n_frames / 60 + 1, base_size))
+        for ax, panel, name in zip(axs, panels, ("A-sust", "RG", "YV", "A-trans")):
+            ax.imshow(panel, cmap=cmap, aspect="auto")
+            ax.set_ylabel(name)
+            ax.yaxis.set_major_locator(ticker.FixedLocator(range(0, 2 * len(labels), 2)))
+            ax.yaxis.set_minor_locator(ticker.MultipleLocator(1.0))
+            ax.set_yticklabels(labels)
+            ax.set_xticks([])
+        if not still:                                                 # a time axis under the last panel only
+            last = axs[-1]
+            last.xaxis.set_major_locator(ticker.AutoLocator())
+            last.xaxis.set_major_formatter(lambda x, pos: str(int(x / fps * 1000)))
+            last.xaxis.set_minor_locator(ticker.MultipleLocator(1.0))
+            last.set_xlabel("Time [ms]")
+        right, bar = (0.5, [0.725, 0.1, 0.125, 0.8]) if still else (0.9, [0.925, 0.1, 0.025, 0.8])
+        plt.subplots_adjust(bottom=0.1, right=right, top=0.9)
+        plt.colorbar(plt.cm.ScalarMappable(norm=Normalize(0, jod_max), cmap=cmap), cax=plt.axes(bar), cmap=cmap)
         plt.savefig(fname, bbox_inches="tight")
         plt.close(fig)
 

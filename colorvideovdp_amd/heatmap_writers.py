@@ -1,0 +1,83 @@
+"""Streaming heat-map sinks for `cvvdp.predict_video_source(vs, heatmap_sink=...)`.
+
+The reference returns the whole heat map as one fp16 CPU tensor (cvvdp_metric.py:344,396-401) and its command line turns
+it into an .mp4 through an ffmpeg pipe or into a .png (run_cvvdp.py:44-78,349-363).  At 8K x 256 frames that tensor is
+51 GB, so here the metric can hand the frames over block by block instead; these sinks put them on disk with bounded
+memory.  ffmpeg is not a dependency: videos become a numbered PNG sequence (`ffmpeg -i base_%05d.png out.mp4` turns it
+into the reference's format) or one .npy file with the reference's array layout.
+
+A sink is any callable `sink(first_frame, frames)`; `frames` is a float16 CPU tensor [1, 1|3, n, H, W] with values in
+[0, 1] (colour-mapped modes) that is only valid during the call.
+"""
+import os
+
+import numpy as np
+
+
+def heatmap_to_uint8(frames):
+    """[1, C, n, H, W] fp16 in [0,1] -> [n, H, W, 3] uint8, the conversion of run_cvvdp.py:np2vid / np2img (:62-76)."""
+    a = frames[0].permute(1, 2, 3, 0).float().numpy()            # [n, H, W, C]
+    if a.shape[-1] == 1:
+        a = np.concatenate([a] * 3, -1)
+    return (np.clip(a, 0.0, 1.0) * 255.0).astype(np.uint8)
+
+
+class HeatmapPngWriter:
+    """One 8-bit PNG per frame: `pattern % frame_index`, e.g. "out/clip_heatmap_%05d.png" (needs Pillow)."""
+
+    def __init__(self, pattern):
+        if "%" not in pattern:
+            raise ValueError("the file name pattern needs a frame-number field, e.g. 'heatmap_%05d.png'")
+        self.pattern = pattern
+        self.frames_written = 0
+        d = os.path.dirname(pattern)
+        if d:
+            os.makedirs(d, exist_ok=True)
+
+    def __call__(self, first_frame, frames):
+        from PIL import Image
+        rgb = heatmap_to_uint8(frames)
+        for i in range(rgb.shape[0]):
+            Image.fromarray(rgb[i]).save(self.pattern % (first_frame + i))
+            self.frames_written += 1
+
+    def close(self):
+        pass
+
+
+class HeatmapNpyWriter:
+    """The reference's `stats["heatmap"]` array ([1, C, F, H, W] float16) as a .npy file, written through a memory map."""
+
+    def __init__(self, path, n_frames, height, width, channels=3):
+        d = os.path.dirname(path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        self.path = path
+        self.mm = np.lib.format.open_memmap(path, mode="w+", dtype=np.float16, shape=(1, channels, n_frames, height, width))
+        self.frames_written = 0
+
+    def __call__(self, first_frame, frames):
+        n = frames.shape[2]
+        self.mm[:, :, first_frame:first_frame + n] = frames.numpy()
+        self.frames_written += n
+
+    def close(self):
+        self.mm.flush()
+        del self.mm
+
+
+class HeatmapFrameMeans:
+    """Keeps only the per-frame mean of every colour plane (cheap sink for benchmarks and tests)."""
+
+    def __init__(self):
+        self.means = {}
+        self.frames_seen = 0
+
+    def __call__(self, first_frame, frames):
+        m = frames[0].float().mean(dim=(2, 3)).numpy()           # [C, n]
+        for i in range(m.shape[1]):
+            self.means[first_frame + i] = m[:, i].copy()
+        self.frames_seen += m.shape[1]
+
+    def close(self):
+        pass

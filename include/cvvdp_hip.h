@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CVVDP_ABI_VERSION 5
+#define CVVDP_ABI_VERSION 6
 #define CVVDP_MAX_FILTER_LEN 65 /* 0.25 s at up to 256 fps, cvvdp_metric.py:1059 */
 #define CVVDP_MAX_LEVELS 16
 #define CVVDP_MAX_WINDOW 256    /* filter_len - 1 + frames per block */
@@ -163,6 +163,14 @@ typedef struct cvvdp_yuv_format {
 int cvvdp_process_block_yuv(cvvdp_handle* h, const void* dev_test, const void* dev_ref, const cvvdp_yuv_format* fmt,
                             int32_t raw_first, const int32_t* hist_src, int32_t n_frames, int32_t q_frame_offset,
                             void* stream);
+
+/* Sources that deliver temporally pre-filtered channels (vid_source.is_temporally_filtered, cvvdp_metric.py:470-488):
+ * frames are fp32 [B, 4, n, H, W] in colour space 'DKLd65_trans' (Y-sustained, RG, YV, Y-transient; element strides in
+ * B,C,F,H,W order) and go straight into the 8 level-0 planes (test channel c -> plane 2c, reference -> 2c+1), bypassing
+ * the sliding window and the temporal FIR; then the contrast pyramid and everything after it, as in cvvdp_process_block. */
+int cvvdp_process_block_filtered(cvvdp_handle* h, const void* dev_test, const void* dev_ref,
+                                 const int64_t strides_test[5], const int64_t strides_ref[5], int32_t n_frames,
+                                 int32_t q_frame_offset, void* stream);
 
 /* Image variant: pyramid, CSF, masking, pooling of the planes written by cvvdp_put_image. */
 int cvvdp_process_image(cvvdp_handle* h, void* stream);

@@ -369,3 +369,218 @@ def test_filter_lengths_without_their_own_kernel(fps):
         np.testing.assert_allclose(qs[0], ostats["Q_per_ch"], rtol=2e-4, atol=2e-6)
         for q in qs[1:]:
             np.testing.assert_array_equal(qs[0], q)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the clips bench.py times, whole (not prefixes), against the real reference (oracle/make_goldens_bench.py)
+@pytest.mark.parametrize("name", __import__("conftest").bench_cases())
+def test_bench_clip_against_reference(name):
+    """BASELINE.json's configurations at their own geometry: the full 1080p x 64 and 4K x 64 fp32 bench clips, the 4K x 256
+    clip (configs[2], uint8) and the 8K PQ heat-map outputs (configs[4]) against outputs of the real reference on the same
+    samples (regenerated from the seed on the CPU and verified by checksum)."""
+    import bench
+    import colorvideovdp_amd as cv
+    g = load_golden(name)
+    W, H, F, fps, disp, dtype = int(g["width"]), int(g["height"]), int(g["frames"]), float(g["fps"]), str(g["display"]), str(g["dtype"])
+    heat = str(g["heatmap_mode"]) if "heatmap_mode" in g else None
+    clip = bench.ResidentClip(F, 0, F, H, W, fps, dtype, torch.device("cuda"), gen="cpu")
+    if (clip.checksum_test, clip.checksum_ref) != (int(g["checksum_test"]), int(g["checksum_ref"])):
+        pytest.skip("this torch build's CPU generator does not reproduce the fixture's synthetic frames")
+    m = cv.cvvdp(display_name=disp, heatmap=heat)
+    jod, stats = m.predict_video_source(clip)
+    assert m.last_block_frames == min(64, F) or heat is not None       # the geometry the bench runs
+    assert abs(float(jod) - float(g["jod"])) <= JOD_TOL
+    np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(stats["rho_band"], g["rho_band"], rtol=1e-12)
+    if heat is not None:
+        hm = stats["heatmap"]
+        assert tuple(hm.shape) == (1, 3, F, H, W) and hm.dtype == torch.float16
+        d = np.abs(hm[0, :, :, ::16, ::16].numpy().astype(np.float32) - g["heatmap_ds"].astype(np.float32))
+        assert (d > 2e-3).mean() < 1e-3 and d.max() <= 2e-2, ((d > 2e-3).mean(), d.max())
+        assert abs(float(hm.float().mean()) - float(g["heatmap_mean"])) < 2e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# host-side outputs and the rest of the class API against the real reference (oracle/make_goldens_outputs.py)
+def _outputs():
+    return load_golden("outputs")
+
+
+@pytest.mark.parametrize("tag", ["vid", "img"])
+def test_distogram_and_features_against_reference(tag, tmp_path):
+    import json
+    o = _outputs()
+    g = load_golden(str(o[f"{tag}_case"]))
+    meta = g["meta"]
+    m = _metric(dict(meta, heatmap=None))
+    jod, stats = m.predict(*_inputs(g), dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+    for jm, key in ((None, f"{tag}_disto_auto"), (10, f"{tag}_disto_10")):
+        panels, _ = m.distogram_data(stats, jod_max=jm)
+        assert panels.shape == o[key].shape
+        np.testing.assert_allclose(panels, o[key], rtol=5e-4, atol=2e-6)       # cvvdp_metric.py:1160-1192: what imshow is handed
+        png = tmp_path / f"d_{jm}.png"
+        m.export_distogram(stats, str(png), jod_max=jm)
+        assert png.stat().st_size > 2000 and png.read_bytes()[:8] == b"\x89PNG\r\n\x1a\n"
+    m.write_features_to_json(stats, str(tmp_path / "f.json"))                # :1112-1127
+    got, want = json.load(open(tmp_path / "f.json")), json.loads(str(o[f"{tag}_features_json"]))
+    assert list(got.keys()) == list(want.keys())
+    for k in want:
+        if isinstance(want[k], list):
+            np.testing.assert_allclose(np.asarray(got[k], dtype=np.float64), np.asarray(want[k], dtype=np.float64), rtol=2e-4, atol=2e-6)
+        else:
+            assert got[k] == want[k], k
+
+
+def test_loss_against_reference():
+    """loss() = 10 - JOD (cvvdp_metric.py:294-298); inference only: gradients are refused, not silently dropped."""
+    import colorvideovdp_amd as cv
+    o = _outputs()
+    g = load_golden(str(o["vid_case"]))
+    meta = g["meta"]
+    m = _metric(dict(meta, heatmap=None))
+    loss = m.loss(*_inputs(g), dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+    assert abs(float(loss) - float(o["vid_loss"])) <= JOD_TOL
+    x = torch.rand((3, 32, 32), requires_grad=True)
+    with pytest.raises(cv.vq_exception):
+        m.loss(x, x.detach(), dim_order="CHW")
+
+
+def test_temporally_filtered_source_bypasses_the_fir():
+    """vid_source.is_temporally_filtered (cvvdp_metric.py:470-488): 4-channel 'DKLd65_trans' frames go straight into the
+    level-0 planes.  Fed with the planes the reference filtered itself, the result must match the reference's; fed with this
+    build's own filtered planes it must reproduce the normal path bit for bit."""
+    from colorvideovdp_amd import _capi
+    o = _outputs()
+    g = load_golden(str(o["vid_case"]))
+    meta = dict(g["meta"], heatmap=None)
+    T, R = torch.from_numpy(o["prefiltered_test"]), torch.from_numpy(o["prefiltered_ref"])     # [4, F, H, W]
+
+    class Pre:
+        is_temporally_filtered = True
+        calls = []
+
+        def __init__(self, T, R):
+            self.T, self.R = T, R
+
+        def get_video_size(self):
+            return (self.T.shape[2], self.T.shape[3], self.T.shape[1])
+
+        def get_frames_per_second(self):
+            return meta["fps"]
+
+        def get_batch_size(self):
+            return 1
+
+        def get_test_frame(self, f, device, colorspace):
+            assert colorspace == "DKLd65_trans"
+            Pre.calls.append(("t", f))
+            return self.T[None, :, f:f + 1].to(device)
+
+        def get_reference_frame(self, f, device, colorspace):
+            assert colorspace == "DKLd65_trans"
+            Pre.calls.append(("r", f))
+            return self.R[None, :, f:f + 1].to(device)
+
+    m = _metric(meta, block_frames=5)
+    jod, stats = m.predict_video_source(Pre(T, R))
+    np.testing.assert_allclose(stats["Q_per_ch"], o["prefiltered_Q_per_ch"], rtol=2e-4, atol=2e-6)
+    assert abs(float(jod) - float(o["prefiltered_jod"])) <= JOD_TOL
+    F = T.shape[1]
+    assert Pre.calls == [x for f in range(F) for x in (("r", f), ("t", f))]      # each frame once, in order, reference first
+    # own planes: run the normal path with the level-0 planes kept, feed them back
+    m2 = _metric(meta)
+    m2.debug_dump = True
+    j_n, s_n = m2.predict(*_inputs(g), dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+    H, W = T.shape[2], T.shape[3]
+    planes = m2.debug_buffer(_capi.BUF_GPYR, 0)[:8 * F * H * W].view(8, F, H, W).cpu()
+    j_p, s_p = _metric(meta).predict_video_source(Pre(planes[0::2].contiguous(), planes[1::2].contiguous()))
+    np.testing.assert_array_equal(s_p["Q_per_ch"], s_n["Q_per_ch"])
+    assert float(j_p) == float(j_n)
+
+
+def test_generic_source_is_read_once_and_in_order():
+    """the reference's file sources are strictly sequential.  A generic video_source (DKL frames, one by one)
+    must see every frame exactly once, in increasing order -- also with symmetric padding (read-ahead) and small blocks --
+    and a display-photometry object of another package on the source must not matter."""
+    from oracle import cvvdp_oracle as orc
+    g = load_golden("vid_u16_67x121x20_30_4k_sym")
+    meta = g["meta"]
+    assert meta["temp_padding"] == "symmetric"
+    disp = orc.DisplayModel.load(meta["display"])
+    tt, rr = orc.to_bcfhw(g["test"], meta["dim_order"]), orc.to_bcfhw(g["ref"], meta["dim_order"])
+    F = tt.shape[2]
+
+    class Foreign:                       # stands in for pycvvdp.vvdp_display_photo_eotf
+        pass
+
+    class Src:
+        dm_photometry = Foreign()
+
+        def __init__(self):
+            self.log = {"t": [], "r": []}
+
+        def get_video_size(self):
+            return (tt.shape[3], tt.shape[4], F)
+
+        def get_batch_size(self):
+            return 1
+
+        def get_frames_per_second(self):
+            return meta["fps"]
+
+        def _frame(self, which, src, frame, colorspace):
+            assert colorspace == "DKLd65"
+            assert frame == (self.log[which][-1] + 1 if self.log[which] else 0), f"random access: {which} {frame} after {self.log[which]}"
+            self.log[which].append(frame)
+            return disp.to_dkl(orc.fetch_frame(src, frame))
+
+        def get_test_frame(self, frame, device, colorspace):
+            return self._frame("t", tt, frame, colorspace).to(device)
+
+        def get_reference_frame(self, frame, device, colorspace):
+            return self._frame("r", rr, frame, colorspace).to(device)
+
+    for nb in (None, 4):
+        src = Src()
+        jod, stats = _metric(meta, block_frames=nb).predict_video_source(src)
+        assert src.log["t"] == list(range(F)) and src.log["r"] == list(range(F))
+        np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(jod.cpu().numpy(), g["jod"], atol=JOD_TOL)
+
+
+def test_streaming_heatmap_sink_matches_the_whole_clip_tensor(tmp_path):
+    """with heatmap_sink the frames arrive block by block (bounded host memory) and are the same fp16 values
+    stats["heatmap"] would hold; the writers put them on disk (PNG sequence, .npy in the reference's layout)."""
+    import colorvideovdp_amd as cv
+    from colorvideovdp_amd import heatmap_writers as hw
+    g = load_golden("vid_u8_135x240x18_60_fhd_raw")
+    meta = dict(g["meta"])
+    t, r = _inputs(g)
+    kw = dict(dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+    for mode in ("raw", "supra-threshold"):
+        meta["heatmap"] = mode
+        _, s_full = _metric(meta).predict(t, r, **kw)
+        full = s_full["heatmap"].clone()
+        F, H, W = full.shape[2], full.shape[3], full.shape[4]
+        got = torch.zeros_like(full)
+        order = []
+
+        def sink(first, frames):
+            order.append((first, frames.shape[2]))
+            got[:, :, first:first + frames.shape[2]] = frames
+
+        m = _metric(meta, block_frames=5)
+        vs = cv.video_source_array(t, r, meta["fps"], dim_order=meta["dim_order"], display_photometry=m.display_photometry)
+        jod, stats = m.predict_video_source(vs, heatmap_sink=sink)
+        assert "heatmap" not in stats
+        assert order == [(f, min(5, F - f)) for f in range(0, F, 5)]
+        assert torch.equal(got, full)                                      # per-frame statistics: blocking does not matter
+        np.testing.assert_array_equal(stats["Q_per_ch"], s_full["Q_per_ch"])
+    npy = hw.HeatmapNpyWriter(str(tmp_path / "hm.npy"), F, H, W, channels=3)
+    png = hw.HeatmapPngWriter(str(tmp_path / "seq" / "hm_%03d.png"))
+    m.predict_video_source(vs, heatmap_sink=lambda f, x: (npy(f, x), png(f, x)))
+    npy.close()
+    assert np.array_equal(np.load(tmp_path / "hm.npy"), full.numpy())
+    assert png.frames_written == F and (tmp_path / "seq" / ("hm_%03d.png" % (F - 1))).stat().st_size > 500
+    with pytest.raises(cv.vq_exception):
+        _metric(dict(meta, heatmap=None)).predict_video_source(vs, heatmap_sink=sink)

@@ -1,0 +1,319 @@
+"""Command line of the MI355X build: `python -m colorvideovdp_amd` / `cvvdp` (console entry in setup.py).
+
+Mirrors the reference's command line (pycvvdp/run_cvvdp.py:83-118 arguments, :120-371 run_on_args) for the path this build
+implements: the `cvvdp` metric on image pairs (PNG / JPEG / anything Pillow reads, 8 or 16 bit), planar .yuv clips (the
+file name carries size, frame rate, bit depth and chroma format, video_source_yuv.py:8-62) and .npy arrays.  Same options,
+same output lines (`cvvdp=9.1234 [JOD]`, or only the number with --quiet), same side outputs (--result CSV, --features
+JSON, --distogram PNG, --heatmap).  Differences, because this image has no ffmpeg and the build is GPU-only:
+  * compressed video files (.mp4, .mkv, ...) are refused with a hint to decode them to .yuv first;
+  * the heat map of a VIDEO is written as a numbered PNG sequence `<base>_heatmap_%05d.png` streamed block by block
+    (`ffmpeg -i <base>_heatmap_%05d.png <base>_heatmap.mp4` gives the reference's file); an image gives `<base>_heatmap.png`;
+  * --device must be a cuda device; --temp-padding 'valid', --full-screen-resize, --temp-resample, --dump-channels and
+    metrics other than cvvdp are not available.
+"""
+import argparse
+import glob
+import logging
+import os
+import shlex
+import sys
+import traceback
+
+import numpy as np
+import torch
+
+from . import heatmap_writers
+from .cvvdp_metric import cvvdp
+from .display_model import vvdp_display_geometry, vvdp_display_photometry
+from .video_source import video_source_array
+from .video_source_yuv import video_source_yuv_file
+from .vq_metric import vq_exception, vq_metric_dict
+
+IMAGE_EXT = (".png", ".jpg", ".jpeg", ".bmp", ".tif", ".tiff", ".ppm", ".pgm")
+VIDEO_EXT = (".mp4", ".mkv", ".mov", ".avi", ".webm", ".m4v", ".y4m")
+
+
+def expand_wildcards(filestrs):
+    """run_cvvdp.py:31-41."""
+    if not isinstance(filestrs, list):
+        return [filestrs]
+    files = []
+    for fs in filestrs:
+        files += sorted(glob.glob(fs)) if "*" in fs else [fs]
+    return files
+
+
+def parse_args(arg_list=None):
+    """The reference's options (run_cvvdp.py:83-118); unsupported ones are accepted and refused with a message."""
+    available = [mm.replace("_", "-") for mm in vq_metric_dict.keys()]
+    p = argparse.ArgumentParser(prog="cvvdp", description="Evaluate ColorVideoVDP on a set of images / videos (MI355X build)")
+    p.add_argument("-t", "--test", type=str, nargs="+", required=False, help="list of test images/videos")
+    p.add_argument("-r", "--ref", type=str, nargs="+", required=False, help="list of reference images/videos")
+    p.add_argument("--device", type=str, default="cuda", help="PyTorch device: 'cuda', 'cuda:0', ... (this build has no CPU path)")
+    p.add_argument("--heatmap", type=str, default="none", help="type of difference map (none, raw, threshold, supra-threshold).")
+    p.add_argument("-g", "--distogram", type=float, default=-1, const=10, nargs="?",
+                   help="generate a distogram; the optional value is the maximum JOD of the colour scale")
+    p.add_argument("-x", "--features", action="store_true", default=False, help="generate JSON files with extracted features")
+    p.add_argument("-o", "--output-dir", type=str, default=None, help="directory for heat maps, distograms and feature files")
+    p.add_argument("--result", type=str, default=None, help="write the predictions to this CSV file")
+    p.add_argument("-c", "--config-paths", type=str, nargs="+", default=[], help="paths to configuration files or directories")
+    p.add_argument("-d", "--display", type=str, default="standard_4k", help="display name, or ? to print the list of models")
+    p.add_argument("-n", "--nframes", type=int, default=-1, help="the number of video frames to compare")
+    p.add_argument("--count-frames", action="store_true", default=False, help="(accepted; frame counts of .yuv / .npy inputs are exact)")
+    p.add_argument("-f", "--full-screen-resize", choices=["bilinear", "bicubic", "nearest", "area"], default=None, help="not available in this build")
+    p.add_argument("-m", "--metric", choices=available, nargs="+", default=["cvvdp"], help="metric(s) to run (this build: cvvdp)")
+    p.add_argument("--temp-padding", choices=["replicate", "symmetric", "valid"], default="symmetric", help="temporal padding of the first frames")
+    p.add_argument("--pix-per-deg", type=float, default=None, help="overwrite the display geometry with this pixels-per-degree value")
+    p.add_argument("--fps", type=float, default=None, help="frames per second (required for .npy videos; overrides the .yuv file name)")
+    p.add_argument("--frames", type=str, default=None, help="not available in this build (frame ranges of image sequences)")
+    p.add_argument("--gpu-mem", type=float, default=None, help="how much GPU memory may be used, in GB")
+    p.add_argument("-q", "--quiet", action="store_true", default=False, help="print only the final JOD value")
+    p.add_argument("-v", "--verbose", action="store_true", default=False, help="print extra information")
+    p.add_argument("--debug", action="store_true", default=False, help="print the stack trace of errors")
+    p.add_argument("--ffmpeg-cc", action="store_true", default=False, help="(accepted, no effect)")
+    p.add_argument("--temp-resample", type=float, nargs="?", default=-1, const=0, help="not available in this build")
+    p.add_argument("-i", "--interactive", action="store_true", default=False, help="read command lines from the standard input, one per line")
+    p.add_argument("--dump-channels", nargs="+", choices=["temporal", "lpyr", "difference"], default=None, help="not available in this build")
+    return p.parse_args(arg_list)
+
+
+def _png_is_16bit_colour(fname):
+    with open(fname, "rb") as f:
+        head = f.read(26)
+    return head[:8] == b"\x89PNG\r\n\x1a\n" and head[12:16] == b"IHDR" and head[24] == 16 and head[25] in (2, 6)
+
+
+def _read_png16(fname):
+    """16-bit RGB(A) PNG -> uint16 [H, W, 3].  Pillow reduces these to 8 bit, which moves the metric by several 1e-3 JOD
+    (the reference's own example image, example_media/wavy_facade.png, is such a file), so they are decoded here:
+    zlib stream + the five PNG row filters (PNG specification, section 9)."""
+    import struct
+    import zlib
+    data = open(fname, "rb").read()
+    pos, idat = 8, b""
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+        if typ == b"IHDR":
+            w, h, depth, ctype, _, _, interlace = struct.unpack(">IIBBBBB", body)
+            if interlace:
+                raise vq_exception(f"'{fname}': interlaced 16-bit PNGs are not supported")
+        elif typ == b"IDAT":
+            idat += body
+        elif typ == b"IEND":
+            break
+    ch = 3 if ctype == 2 else 4
+    bpp, stride = 2 * ch, w * 2 * ch
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, stride + 1)
+    out = np.zeros((h, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(h):
+        ft, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:                                   # Up
+            cur = (line + prev) & 255
+        elif ft == 1:                                   # Sub: a running sum per byte lane
+            cur = (np.cumsum(line.reshape(w, bpp), axis=0) & 255).reshape(-1)
+        else:                                           # Average / Paeth depend on the pixel to the left: sequential
+            cur = line.copy()
+            for i in range(stride):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                if ft == 3:
+                    pred = (a + b) >> 1
+                else:
+                    c = prev[i - bpp] if i >= bpp else 0
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[i] = (cur[i] + pred) & 255
+        out[y] = cur
+        prev = cur
+    px = out.reshape(h, w, ch, 2).astype(np.uint16)
+    return np.ascontiguousarray(((px[..., 0] << 8) | px[..., 1])[..., :3])
+
+
+def _read_image(fname):
+    """8- or 16-bit image file -> uint8 / uint16 array [H, W, C] (the reference reads them with imageio, video_source_file.py)."""
+    if _png_is_16bit_colour(fname):
+        return _read_png16(fname)
+    from PIL import Image
+    with Image.open(fname) as im:
+        if im.mode in ("I;16", "I;16B", "I;16L", "I"):
+            a = np.asarray(im).astype(np.uint16)[..., None]
+        elif im.mode in ("L", "P", "1"):
+            a = np.asarray(im.convert("L"))[..., None]
+        else:
+            a = np.asarray(im.convert("RGB"))
+            if a.dtype not in (np.uint8, np.uint16):
+                a = a.astype(np.uint8)
+    return np.ascontiguousarray(a)
+
+
+def load_source(test_file, ref_file, display_photometry, config_paths, nframes=-1, fps=None):
+    """The reference's video_source_file dispatch (run_cvvdp.py:296-318) for the formats available here."""
+    ext = {os.path.splitext(f)[1].lower() for f in (test_file, ref_file)}
+    if len(ext) != 1:
+        raise vq_exception(f"Test and reference must be files of the same kind ('{test_file}' vs '{ref_file}')")
+    ext = ext.pop()
+    for f in (test_file, ref_file):
+        if not os.path.isfile(f):
+            raise vq_exception(f"File not found: '{f}'")
+    if ext == ".yuv":
+        vs = video_source_yuv_file(test_file, ref_file, display_photometry=display_photometry, frames=nframes, config_paths=config_paths)
+        if fps is not None:
+            vs.test_vidr.avg_fps = vs.reference_vidr.avg_fps = fps
+        return vs
+    if ext in IMAGE_EXT:
+        t, r = _read_image(test_file), _read_image(ref_file)
+        if t.shape != r.shape or t.dtype != r.dtype:
+            raise vq_exception(f"Test and reference images differ in size or bit depth: {t.shape} {t.dtype} vs {r.shape} {r.dtype}")
+        return video_source_array(t, r, 0, dim_order="HWC", display_photometry=display_photometry)
+    if ext == ".npy":
+        t, r = np.load(test_file, mmap_mode="r"), np.load(ref_file, mmap_mode="r")
+        if t.ndim == 3:
+            return video_source_array(np.ascontiguousarray(t), np.ascontiguousarray(r), 0, dim_order="HWC", display_photometry=display_photometry)
+        if t.ndim != 4:
+            raise vq_exception(".npy inputs must be [H, W, C] images or [F, H, W, C] videos")
+        if not fps:
+            raise vq_exception("--fps is required for .npy videos")
+        if nframes > 0:
+            t, r = t[:nframes], r[:nframes]
+        return video_source_array(np.ascontiguousarray(t), np.ascontiguousarray(r), fps, dim_order="FHWC", display_photometry=display_photometry)
+    if ext in VIDEO_EXT:
+        raise vq_exception(f"'{test_file}': compressed video files need ffmpeg, which this build does not use. Decode both clips to planar "
+                           f".yuv first, e.g. `ffmpeg -i clip.mp4 -pix_fmt yuv420p clip_1920x1080_30fps_420p8.yuv`")
+    raise vq_exception(f"Unsupported file type '{ext}'")
+
+
+def run_on_args(args):
+    """run_cvvdp.py:120-371."""
+    logging.basicConfig(format="[%(levelname)s] %(message)s", level=logging.ERROR if args.quiet else (logging.DEBUG if args.verbose else logging.INFO), force=True)
+    args.metric = [mm.replace("-", "_") for mm in args.metric]
+    if args.display == "?":
+        vvdp_display_photometry.list_displays(args.config_paths)
+        return
+    if args.test is None or args.ref is None:
+        logging.error("Paths to both test and reference content needs to be specified.")
+        return
+    for opt, what in ((args.full_screen_resize, "--full-screen-resize"), (args.frames, "--frames"), (args.dump_channels, "--dump-channels")):
+        if opt is not None:
+            raise vq_exception(f"{what} is not available in the MI355X build")
+    if args.temp_resample >= 0:
+        raise vq_exception("--temp-resample is not available in the MI355X build")
+    if args.temp_padding == "valid":
+        raise vq_exception("--temp-padding valid is not available in the MI355X build (replicate or symmetric)")
+    device = args.device.lower()
+    if not device.startswith("cuda"):
+        raise vq_exception(f"--device {args.device}: the MI355X build runs on a cuda (HIP) device only")
+    if not torch.cuda.is_available():
+        raise vq_exception("no HIP device available; this build has no CPU path")
+    device = torch.device(device)
+    logging.info("Running on device: " + str(device))
+    if args.heatmap == "none":
+        args.heatmap = None
+    if args.heatmap and args.heatmap not in ("raw", "threshold", "supra-threshold"):
+        logging.error('The recognized heatmap types are: "none", "raw", "threshold" and "supra-threshold"')
+        sys.exit()
+    args.test, args.ref = expand_wildcards(args.test), expand_wildcards(args.ref)
+    n_test, n_ref = len(args.test), len(args.ref)
+    if n_test == 0:
+        logging.error("No test images/videos found.")
+        sys.exit()
+    if n_ref == 0:
+        logging.error("No reference images/videos found.")
+        sys.exit()
+    if n_test != n_ref and n_test != 1 and n_ref != 1:
+        logging.error("Pass the same number of reference and test sources, or a single reference (to be used with all test sources), "
+                      "or a single test (to be used with all reference sources).")
+        sys.exit()
+    display_photometry = vvdp_display_photometry.load(args.display, config_paths=args.config_paths)
+    if args.pix_per_deg is None:
+        display_geometry = vvdp_display_geometry.load(args.display, config_paths=args.config_paths)
+    else:
+        display_geometry = vvdp_display_geometry([1024, 1024], ppd=args.pix_per_deg)
+    out_dir = "." if args.output_dir is None else args.output_dir
+    os.makedirs(out_dir, exist_ok=True)
+
+    metrics = []
+    for mm in args.metric:
+        if mm not in vq_metric_dict:
+            raise RuntimeError(f"Unknown metric {mm}")
+        fv = vq_metric_dict[mm](display_photometry=display_photometry, display_geometry=display_geometry, device=device, heatmap=args.heatmap,
+                                temp_padding=args.temp_padding, config_paths=args.config_paths, gpu_mem=args.gpu_mem, quiet=args.quiet)
+        fv.train(False)
+        metrics.append(fv)
+        info = fv.get_info_string()
+        if info is not None:
+            logging.info("When reporting metric results, please include the following information:")
+            logging.info(info)
+
+    res_fh = None
+    if args.result is not None:
+        res_fh = open(args.result, "w")
+        res_fh.write("test, reference" + "".join(", " + mm.short_name() for mm in metrics) + "\n")
+    try:
+        for kk in range(max(n_test, n_ref)):
+            test_file, ref_file = args.test[min(kk, n_test - 1)], args.ref[min(kk, n_ref - 1)]
+            if res_fh is not None:
+                res_fh.write(f"{test_file}, {ref_file}")
+            logging.info(f"Predicting the quality of '{test_file}' compared to '{ref_file}'")
+            for mm in metrics:
+                vs = load_source(test_file, ref_file, display_photometry, args.config_paths, nframes=args.nframes, fps=args.fps)
+                base = os.path.splitext(os.path.basename(test_file))[0]
+                mm.set_base_fname(os.path.join(out_dir, base))
+                is_video = vs.get_video_size()[2] > 1
+                sink = None
+                if args.heatmap and is_video:          # streamed to disk block by block: bounded host memory at any clip length
+                    pattern = os.path.join(out_dir, base + "_heatmap_%05d.png")
+                    logging.info(f"Writing heat map frames '{pattern}' ...")
+                    sink = heatmap_writers.HeatmapPngWriter(pattern)
+                Q_pred, stats = mm.predict_video_source(vs, heatmap_sink=sink) if sink is not None else mm.predict_video_source(vs)
+                q = Q_pred.item()
+                print(f"{q:0.4f}" if args.quiet else f"{mm.short_name()}={q:0.4f} [{mm.quality_unit()}]")
+                if res_fh is not None:
+                    res_fh.write(f", {q}")
+                if args.features and stats is not None:
+                    dest = os.path.join(out_dir, base + "_fmap.json")
+                    logging.info("Writing feature map '" + dest + "' ...")
+                    mm.write_features_to_json(stats, dest)
+                if args.heatmap and not is_video and stats is not None:
+                    dest = os.path.join(out_dir, base + "_heatmap.png")
+                    logging.info("Writing heat map '" + dest + "' ...")
+                    from PIL import Image
+                    Image.fromarray(heatmap_writers.heatmap_to_uint8(stats["heatmap"])[0]).save(dest)
+                if args.distogram != -1:
+                    dest = os.path.join(out_dir, base + "_distogram.png")
+                    logging.info("Writing distogram '" + dest + "' ...")
+                    mm.export_distogram(stats, dest, jod_max=args.distogram)
+                del stats
+            if res_fh is not None:
+                res_fh.write("\n")
+    finally:
+        if res_fh is not None:
+            res_fh.close()
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    try:
+        if args.interactive:
+            while True:
+                line = sys.stdin.readline()
+                if not line:
+                    break
+                args = parse_args(shlex.split(line))
+                run_on_args(args)
+        else:
+            run_on_args(args)
+    except vq_exception as ex:
+        logging.error(str(ex))
+        if args.debug:
+            traceback.print_exc()
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -53,7 +53,8 @@ def distogram_arrays(m, stats, jod_max):
     matplotlib.axes.Axes.imshow = spy
     try:
         with tempfile.TemporaryDirectory() as d:
-            m.export_distogram(dict(stats), os.path.join(d, "d.png"), jod_max=jod_max)
+            # (a fresh copy: on the CPU the reference scales stats['Q_per_ch'] in place -- torch.as_tensor shares the array)
+            m.export_distogram({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in stats.items()}, os.path.join(d, "d.png"), jod_max=jod_max)
             size = os.path.getsize(os.path.join(d, "d.png"))
     finally:
         matplotlib.axes.Axes.imshow = orig

@@ -1,0 +1,97 @@
+"""The `cvvdp` command line (colorvideovdp_amd/run_cvvdp.py) against the reference's command-line contract
+(pycvvdp/run_cvvdp.py:83-371): options, output lines, CSV / JSON / PNG side outputs, on committed fixtures."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+JOD_TOL = 1e-3
+
+
+def _write_yuv(g, d):
+    ft, fr = os.path.join(d, str(g["fname_test"])), os.path.join(d, str(g["fname_ref"]))
+    g["test"].tofile(ft)
+    g["ref"].tofile(fr)
+    return ft, fr
+
+
+def test_arguments_mirror_the_reference():
+    from colorvideovdp_amd import run_cvvdp as rc
+    a = rc.parse_args(["--test", "a.png", "--ref", "b.png"])
+    # run_cvvdp.py:88-117 defaults
+    assert (a.device, a.heatmap, a.distogram, a.features, a.display, a.nframes, a.metric, a.temp_padding, a.quiet, a.interactive) == \
+        ("cuda", "none", -1, False, "standard_4k", -1, ["cvvdp"], "symmetric", False, False)
+    a = rc.parse_args(["-t", "a.png", "b.png", "-r", "r.png", "-g", "-x", "-o", "out", "--result", "r.csv", "-d", "standard_fhd", "-q", "--heatmap", "threshold"])
+    assert a.test == ["a.png", "b.png"] and a.distogram == 10 and a.features and a.output_dir == "out" and a.result == "r.csv" and a.quiet
+    assert rc.parse_args(["-g", "7.5"]).distogram == 7.5
+    assert rc.expand_wildcards(["x.png"]) == ["x.png"]
+
+
+def test_refusals_need_no_gpu(tmp_path, capsys):
+    from colorvideovdp_amd import run_cvvdp as rc
+    for extra in (["--device", "cpu"], ["--temp-padding", "valid"], ["--temp-resample"], ["--full-screen-resize", "bilinear"]):
+        assert rc.main(["-t", "a.png", "-r", "b.png"] + extra) == 1          # vq_exception -> logged, exit code 1
+    assert rc.main([]) == 0                                                   # "Paths to both ... need to be specified", like the reference
+    img = (np.arange(64 * 48 * 3).reshape(48, 64, 3) % 251).astype(np.uint8)
+    from PIL import Image
+    Image.fromarray(img).save(tmp_path / "a.png")
+    assert np.array_equal(rc._read_image(str(tmp_path / "a.png")), img)
+    Image.fromarray(img[..., 0]).save(tmp_path / "g.png")
+    assert rc._read_image(str(tmp_path / "g.png")).shape == (48, 64, 1)
+
+
+@pytest.mark.gpu
+def test_yuv_pair_with_all_side_outputs(tmp_path, capsys):
+    from colorvideovdp_amd import run_cvvdp as rc
+    g = load_golden("yuv420_8b_709_64x48x10_30")
+    ft, fr = _write_yuv(g, str(tmp_path))
+    out = tmp_path / "out"
+    rc_code = rc.main(["--test", ft, "--ref", fr, "--display", str(g["display"]), "--temp-padding", "replicate", "--heatmap", "supra-threshold",
+                       "--distogram", "--features", "--result", str(tmp_path / "res.csv"), "--output-dir", str(out)])
+    assert rc_code == 0
+    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("cvvdp=")]
+    assert len(line) == 1 and line[0].endswith(" [JOD]")                       # run_cvvdp.py:326-330
+    jod = float(line[0][len("cvvdp="):-len(" [JOD]")])
+    assert abs(jod - float(g["jod"])) <= JOD_TOL and len(line[0].split("=")[1].split()[0].split(".")[1]) == 4
+    base = os.path.splitext(os.path.basename(ft))[0]
+    csv = open(tmp_path / "res.csv").read().splitlines()
+    assert csv[0] == "test, reference, cvvdp" and csv[1].startswith(f"{ft}, {fr}, ") and abs(float(csv[1].split(", ")[2]) - float(g["jod"])) <= JOD_TOL
+    fmap = json.load(open(out / f"{base}_fmap.json"))
+    assert fmap["N_frames"] == int(g["frames"]) and np.asarray(fmap["t0_b0"]).shape == (1, int(g["frames"]))
+    np.testing.assert_allclose(np.asarray(fmap["t3_b1"])[0], g["Q_per_ch"][0, 3, :, 1], rtol=2e-4, atol=2e-6)
+    assert (out / f"{base}_distogram.png").stat().st_size > 2000
+    frames = sorted(f for f in os.listdir(out) if f.startswith(base + "_heatmap_"))
+    assert len(frames) == int(g["frames"]) and frames[0].endswith("_00000.png")
+    from PIL import Image
+    assert Image.open(out / frames[0]).size == (int(g["width"]), int(g["height"]))
+
+
+@pytest.mark.gpu
+def test_image_pairs_quiet_and_interactive(tmp_path, capsys, monkeypatch):
+    import io
+    from PIL import Image
+    from colorvideovdp_amd import run_cvvdp as rc
+    g = load_golden("img_u8_256x256_fhd")
+    meta = g["meta"]
+    assert meta["dim_order"] == "HWC"
+    Image.fromarray(g["test"]).save(tmp_path / "t.png")
+    Image.fromarray(g["ref"]).save(tmp_path / "r.png")
+    args = ["-t", str(tmp_path / "t.png"), "-r", str(tmp_path / "r.png"), "-d", meta["display"], "-q", "--heatmap", "threshold", "-o", str(tmp_path)]
+    assert rc.main(args) == 0
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 1 and abs(float(out[0]) - float(g["jod"])) <= JOD_TOL      # --quiet: the number only (run_cvvdp.py:327)
+    hm = np.asarray(Image.open(tmp_path / "t_heatmap.png"))
+    assert hm.shape == (256, 256, 3)
+    want = (np.clip(g["heatmap"][0, :, 0].astype(np.float32).transpose(1, 2, 0), 0, 1) * 255).astype(np.uint8)   # np2img, run_cvvdp.py:66-76
+    assert (np.abs(hm.astype(int) - want.astype(int)) > 1).mean() < 1e-3
+    # a .npy pair, two lines through --interactive
+    np.save(tmp_path / "t.npy", g["test"]); np.save(tmp_path / "r.npy", g["ref"])
+    line = f"-t {tmp_path / 't.npy'} -r {tmp_path / 'r.npy'} -d {meta['display']} -q\n"
+    monkeypatch.setattr("sys.stdin", io.StringIO(line + line))
+    assert rc.main(["--interactive"]) == 0
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 2 and all(abs(float(o) - float(g["jod"])) <= JOD_TOL for o in out)
+    assert rc.main(["-t", str(tmp_path / "t.png"), "-r", str(tmp_path / "clip.mp4")]) == 1   # mixed / unsupported kinds are refused

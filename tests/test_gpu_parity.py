@@ -506,8 +506,9 @@ def test_generic_source_is_read_once_and_in_order():
     g = load_golden("vid_u16_67x121x20_30_4k_sym")
     meta = g["meta"]
     assert meta["temp_padding"] == "symmetric"
-    disp = orc.DisplayModel.load(meta["display"])
-    tt, rr = orc.to_bcfhw(g["test"], meta["dim_order"]), orc.to_bcfhw(g["ref"], meta["dim_order"])
+    disp = orc.Display(meta["display"])
+    t, r = _inputs(g)
+    tt, rr = orc.to_bcfhw(t, meta["dim_order"]), orc.to_bcfhw(r, meta["dim_order"])
     F = tt.shape[2]
 
     class Foreign:                       # stands in for pycvvdp.vvdp_display_photo_eotf

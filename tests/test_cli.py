@@ -74,9 +74,10 @@ def test_image_pairs_quiet_and_interactive(tmp_path, capsys, monkeypatch):
     import io
     from PIL import Image
     from colorvideovdp_amd import run_cvvdp as rc
-    g = load_golden("img_u8_256x256_fhd")
+    g = load_golden("img_u8_64x96_fhd_thr")             # an image case with a threshold heat map from the reference
     meta = g["meta"]
-    assert meta["dim_order"] == "HWC"
+    assert meta["dim_order"] == "HWC" and meta["heatmap"] == "threshold"
+    H, W = g["test"].shape[:2]
     Image.fromarray(g["test"]).save(tmp_path / "t.png")
     Image.fromarray(g["ref"]).save(tmp_path / "r.png")
     args = ["-t", str(tmp_path / "t.png"), "-r", str(tmp_path / "r.png"), "-d", meta["display"], "-q", "--heatmap", "threshold", "-o", str(tmp_path)]
@@ -84,9 +85,9 @@ def test_image_pairs_quiet_and_interactive(tmp_path, capsys, monkeypatch):
     out = capsys.readouterr().out.strip().splitlines()
     assert len(out) == 1 and abs(float(out[0]) - float(g["jod"])) <= JOD_TOL      # --quiet: the number only (run_cvvdp.py:327)
     hm = np.asarray(Image.open(tmp_path / "t_heatmap.png"))
-    assert hm.shape == (256, 256, 3)
+    assert hm.shape == (H, W, 3)
     want = (np.clip(g["heatmap"][0, :, 0].astype(np.float32).transpose(1, 2, 0), 0, 1) * 255).astype(np.uint8)   # np2img, run_cvvdp.py:66-76
-    assert (np.abs(hm.astype(int) - want.astype(int)) > 1).mean() < 1e-3
+    assert (np.abs(hm.astype(int) - want.astype(int)) > 1).mean() < 1e-2
     # a .npy pair, two lines through --interactive
     np.save(tmp_path / "t.npy", g["test"]); np.save(tmp_path / "r.npy", g["ref"])
     line = f"-t {tmp_path / 't.npy'} -r {tmp_path / 'r.npy'} -d {meta['display']} -q\n"

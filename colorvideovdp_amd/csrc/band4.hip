@@ -41,6 +41,7 @@ constexpr int B4_VE = 136;         // s_ve row: element 4+i = coarse column cb+i
 struct f4 { float v[4]; };
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };   // 16 bytes at 4-byte alignment (rows of any width)
 
 __device__ __forceinline__ f4 lds_read4(const float* p) {
   const float4 q = *reinterpret_cast<const float4*>(p);
@@ -56,7 +57,7 @@ __device__ __forceinline__ int refl(int i, int n) {
   return i;
 }
 
-template <int NCH, bool HEAT>
+template <int NCH, bool HEAT, bool RAGGED>
 __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   constexpr int NP = 2 * NCH;
   // s_ve is a ring of two rows (row parity): row r+1 is written during phase 1 of row r, so that phase 2 can derive
@@ -88,7 +89,15 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   const int H = a.H, W = a.W, Hc = a.Hc, Wc = a.Wc;
   const int x0 = strip * B4_SW;
   const int fc0 = x0 - B4_HALO + 4 * j;             // first of this lane's 4 columns
-  const bool in_img = fc0 >= 0 && fc0 < W;          // all four in or all four out (W % 4 == 0)
+  const bool in_img = fc0 >= 0 && fc0 < W;          // at least the first of the four columns is inside the image
+  // Ragged right edge (W % 4 != 0, any parity): one lane of the last strip holds 1..3 valid columns.  Its 16-byte load is
+  // clamped to the last four columns of the row and shifted into place; its invalid columns carry finite garbage that the
+  // reflect padding overwrites (s_m) or that is masked out (pooling, stores).  Everything ragged sits behind block-uniform
+  // branches: full strips and W % 4 == 0 run the same instructions as before.
+  // RAGGED is a separate instantiation (launch_band4 picks it when W % 8 != 0): the aligned kernel keeps its register budget.
+  const bool ragged_blk = RAGGED && (W & 3) != 0 && x0 + B4_SW >= W;
+  const int g_shift = RAGGED && in_img ? max(fc0 - (W - 4), 0) : 0;      // 1..3 in the partial lane: loaded element i+g_shift is column fc0+i
+  const int n_valid = RAGGED ? (in_img ? min(W - fc0, 4) : 0) : 4;
   const bool interior = j >= 2 && j < 62 && fc0 < W;  // columns whose result is pooled
   const int cb = (x0 - B4_HALO) / 2;                // coarse column of s_ve[.][1]
   const int ys = seg * a.seg_h, ye = min(H, ys + a.seg_h);   // ys is even (core.cpp keeps seg_h even)
@@ -132,18 +141,26 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   // coarse row, requested a row and a half earlier: each coarse row comes from HBM once.  Reflected rows reload the
   // whole window (the loads land in the window registers directly).
   const int cx = min(max(vcx, 0), Wc - 4);
-  const bool clampL = vcx < 0, clampR = vcx >= Wc;
+  const bool clampL = vcx < 0;
   const bool edge_block = cb < 0 || cb + 128 > Wc;   // block-uniform: only edge strips pay for the replicate selects
   const float* gcl = gcp + (int64_t)(j >> 5) * gcps + cx;         // the lane's plane and chunk (64-bit: plane strides can pass 4 GB)
   float4 cA, cB, cC;        // coarse rows my-1, my, my+1 (clamped) of the chunk
   v4f cN = 0.0f;            // the next row up, in flight (hand-managed load, see STREAM LOADS)
+  bool reloaded = false;    // scalar: the last reload request did load (its rows are still raw)
   auto coarse_load = [&](int row) -> float4 {
-    return *reinterpret_cast<const float4*>(gcl + (int64_t)row * Wc);
+    const f4u q = *reinterpret_cast<const f4u*>(gcl + (int64_t)row * Wc);
+    return make_float4(q.x, q.y, q.z, q.w);
   };
-  auto replicate = [&](float4 v) -> float4 {     // replicate column 0 / Wc-1 for chunks left / right of the image
-    if (edge_block && (clampL || clampR)) {
-      const float rv = clampL ? v.x : v.w;
-      v = make_float4(rv, rv, rv, rv);
+  // chunk reaching past column Wc-1: element i is loaded element min(i+c_shift, 3); with Wc % 4 == 0 a chunk is all in or all out
+  const int c_shift = RAGGED ? min(max(vcx - (Wc - 4), 0), 3) : (vcx >= Wc ? 3 : 0);
+  auto replicate = [&](float4 v) -> float4 {     // replicate column 0 / Wc-1 for chunks left of / reaching past the image
+    if (edge_block && (clampL || c_shift > 0)) {
+      if (clampL) {
+        v = make_float4(v.x, v.x, v.x, v.x);
+      } else {
+        const float e0_ = c_shift == 1 ? v.y : (c_shift == 2 ? v.z : v.w), e1_ = c_shift == 1 ? v.z : v.w;
+        v = make_float4(e0_, e1_, v.w, v.w);
+      }
     }
     return v;
   };
@@ -153,7 +170,8 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     if constexpr (!decltype(fast)::value) {
       // (an odd row inside the image shares its predecessor's window here too: the rolling loop that may follow finishes
       // such a row without touching the window, so it must not be handed a raw, un-replicated reload)
-      if (!(decltype(odd)::value && q >= 1 && q <= H - 1)) {
+      reloaded = !(decltype(odd)::value && q >= 1 && q <= H - 1);
+      if (reloaded) {
         const int my = min(refl(q, H), H - 1) >> 1;
         cA = coarse_load(max(my - 1, 0));
         cB = coarse_load(my);
@@ -165,7 +183,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   auto coarse_finish = [&](int buf, auto odd, auto fast) {
     if constexpr (decltype(fast)::value) {
       if constexpr (!decltype(odd)::value) { cA = cB; cB = cC; cC = replicate(make_float4(cN.x, cN.y, cN.z, cN.w)); }
-    } else {
+    } else if (reloaded) {                          // raw rows: once only (a shifted chunk must not be shifted again)
       cA = replicate(cA); cB = replicate(cB); cC = replicate(cC);
     }
     const float m0[4] = {cA.x, cA.y, cA.z, cA.w}, m1[4] = {cB.x, cB.y, cB.z, cB.w}, m2[4] = {cC.x, cC.y, cC.z, cC.w};
@@ -261,10 +279,18 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
       // Du = X/(1+M); D = dmax*Du/(dmax+Du) = X / ((1+M) + X/dmax): one reciprocal (:855-856, :949-950)
       const float X = fast_pow(d.v[i], a.mask_p) - a.eps_p;      // s_d holds |T'-R'| + eps
       D[i] = X * fast_rcp(X * inv_dmax + M1);
-      acc += D[i] * (D[i] + 2.0f * kEps);                        // (D+eps)^2 - eps^2
     }
-    if (a.ddump) *reinterpret_cast<float4*>(a.ddump + (int64_t)c * a.items_cap * P + (int64_t)item * P + (int64_t)y * W + fc0) =
-        make_float4(D[0], D[1], D[2], D[3]);
+    if (ragged_blk) {                                              // columns right of the image do not exist
+#pragma unroll
+      for (int i = 1; i < 4; ++i) D[i] = i < n_valid ? D[i] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc += D[i] * (D[i] + 2.0f * kEps);   // (D+eps)^2 - eps^2
+    if (a.ddump) {
+      float* dd = a.ddump + (int64_t)c * a.items_cap * P + (int64_t)item * P + (int64_t)y * W + fc0;
+      if (n_valid == 4) *reinterpret_cast<f4u*>(dd) = f4u{D[0], D[1], D[2], D[3]};
+      else for (int i = 0; i < n_valid; ++i) dd[i] = D[i];
+    }
     if constexpr (HEAT) {   // this channel's term of the per-pixel channel norm (cvvdp_metric.py:728-734)
       float ht[4];
 #pragma unroll
@@ -334,11 +360,12 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   // image-edge mirror roles (see the contrast stage): left edge = lanes with fc0 = 0 / 4 (strip 0), right edge = lanes
   // with fc0 = W-8 / W-4 (last strip); W >= 16 keeps them apart
   const bool mir_block = strip == 0 || x0 + B4_SW >= W;
+  const bool mir_any = RAGGED && (W & 3) != 0;       // right edge not on a lane boundary: per-column mirror writes
   int mir_kind = 0, mir_base = 0;
   if (strip == 0 && (fc0 == 0 || fc0 == 4)) { mir_kind = fc0 == 0 ? 1 : 2; mir_base = B4_HALO - (fc0 == 0 ? 1 : 4); }
-  if (fc0 == W - 8 || fc0 == W - 4) {
-    mir_kind = fc0 == W - 8 ? 1 : 2;
-    mir_base = 2 * (W - 1) - (fc0 + (fc0 == W - 8 ? 1 : 0)) - (x0 - B4_HALO);
+  if (!mir_any && (fc0 == W - 8 || fc0 == W - 4)) {
+    const int base = 2 * (W - 1) - (fc0 + (fc0 == W - 8 ? 1 : 0)) - (x0 - B4_HALO);
+    if (base < 256) { mir_kind = fc0 == W - 8 ? 1 : 2; mir_base = base; }   // (the right halo lanes of the strip before the last can hold these columns too: out of its range)
   }
 
   // ---- prologue: window + expand of the first row, g rows of the first two rows, luminance terms of the first row
@@ -363,6 +390,12 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     if constexpr (ODD) B4_WAIT_ODD(); else B4_WAIT_EVEN();
     v4f pT, pR;
     if constexpr (ODD) { pT = p1T; pR = p1R; } else { pT = p0T; pR = p0R; }
+    if (ragged_blk) {                                 // partial lane: its load was clamped to the row's last four columns
+      if (g_shift > 0) {
+        pT = v4f{g_shift == 1 ? pT.y : (g_shift == 2 ? pT.z : pT.w), g_shift == 1 ? pT.z : pT.w, pT.w, pT.w};
+        pR = v4f{g_shift == 1 ? pR.y : (g_shift == 2 ? pR.z : pR.w), g_shift == 1 ? pR.z : pR.w, pR.w, pR.w};
+      }
+    }
     // ================= phase 1
     const int yprev = r - 1 - B4_R;                  // row whose Mq was published last iteration (ring slot k7, like row r)
     if (interior && yprev >= ys) stage3c(yprev, k7);
@@ -402,6 +435,14 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
           const float v0 = mir_kind == 1 ? m[1] : m[0], v1 = mir_kind == 1 ? m[2] : m[1], v2 = mir_kind == 1 ? m[3] : m[2];
           float* dst = &s_m[c][mir_base];
           dst[0] = v0; dst[-1] = v1; dst[-2] = v2;
+        }
+        if (mir_any) {                                // columns W-7 .. W-2, wherever they fall in the lanes, to 2(W-1)-x
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int x = fc0 + i;
+            const int idx = 2 * (W - 1) - x - (x0 - B4_HALO);
+            if (x >= W - 1 - B4_R && x <= W - 2 && idx < 256) s_m[c][idx] = m[i];
+          }
         }
       }
     }
@@ -504,17 +545,23 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
 #undef B4_WAIT_ODD
 #undef B4_DRAIN
 
+template <bool RAGGED>
+static void launch_band4_w(const BandArgs& a, hipStream_t s) {
+  dim3 grid(8 * a.per_xcd);
+  if (a.dchr) {
+    if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, true, RAGGED>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_band4<3, true, RAGGED>), grid, dim3(192), 0, s, a);
+  } else {
+    if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, false, RAGGED>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_band4<3, false, RAGGED>), grid, dim3(192), 0, s, a);
+  }
+}
+
 void launch_band4(const BandArgs& a0, hipStream_t s) {
   BandArgs a = a0;
   a.per_xcd = (a.n_strip * a.n_seg * a.items + 7) / 8;
-  dim3 grid(8 * a.per_xcd);
-  if (a.dchr) {
-    if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_band4<3, true>), grid, dim3(192), 0, s, a);
-  } else {
-    if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, false>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_band4<3, false>), grid, dim3(192), 0, s, a);
-  }
+  if (a.W & 7) launch_band4_w<true>(a, s);       // a lane of the last strip, or a coarse 4-column chunk, straddles the right image edge
+  else launch_band4_w<false>(a, s);
 }
 
 }  // namespace cvvdp

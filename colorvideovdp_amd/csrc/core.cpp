@@ -306,7 +306,7 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     Level& lv = h->lv[l];
     lv.H = H; lv.W = W; lv.P = (int64_t)H * W;
     lv.blur = pad > 0 && H > pad && W > pad;
-    lv.vec4 = lv.blur && (W % 8 == 0) && W >= 16 && H >= 16;   // k_band4: edge-mirror lanes apart, reflected prefetch rows inside the image
+    lv.vec4 = lv.blur && W >= 16 && H >= 16;   // k_band4 (any width): edge-mirror lanes apart, reflected prefetch rows inside the image
     const int sw = lv.vec4 ? kBand4StripWidth : (lv.blur ? 256 - 2 * pad : 256);
     lv.n_strip = (W + sw - 1) / sw;
     // Row segments.  Every segment recomputes 12 blur-halo rows, so segments should be long; a block marches ~2.6 us

@@ -124,6 +124,50 @@ __device__ __forceinline__ void hreduce_row(const ReduceArgs& a, const float* im
   }
 }
 
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };   // 16 bytes at 4-byte alignment (rows of any width)
+
+// Any width (W % 8 != 0, odd or even): the same arithmetic as hreduce_row<true>, with the image-border logic per sample
+// instead of per 16-byte group.  Threads whose 16 input columns lie inside the image load them as four (unaligned)
+// 16-byte groups; the few threads at the left / right border read sample by sample with clamped addresses and zero masks.
+// The last output column Wo-1 can sit in any of the thread's four slots, and its two edge samples (columns W-1, W-2,
+// lpyr_dec.py:206-209) are fetched separately, so that no register array is indexed dynamically.
+__device__ __forceinline__ void hreduce_row_any(const ReduceArgs& a, const float* img, int y, int ox, float (&h)[4]) {
+  const int ix = 2 * ox - 4;
+  const float* row = img + (int64_t)min(max(y, 0), a.H - 1) * a.W;
+  const float my = (y >= 0 && y < a.H) ? 1.0f : 0.0f;
+  float v[16];
+  if (ix >= 0 && ix + 16 <= a.W) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f4u t = *reinterpret_cast<const f4u*>(row + ix + 4 * q);
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int x = ix + e;
+      v[e] = row[min(max(x, 0), a.W - 1)] * ((x >= 0 && x < a.W) ? 1.0f : 0.0f);
+    }
+  }
+  const float k0 = a.k[0] * my, k1 = a.k[1] * my, k2 = a.k[2] * my, k3 = a.k[3] * my, k4 = a.k[4] * my;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) h[j] = dot5(v[2 * j + 2], v[2 * j + 3], v[2 * j + 4], v[2 * j + 5], v[2 * j + 6], k0, k1, k2, k3, k4);
+  if (ox == 0) h[0] += dot2(v[4], v[5], k1, k0);                    // lpyr_dec.py:205 (columns 0 and 1)
+  const int jl = a.Wo - 1 - ox;                                     // slot of the last output column, if it is this thread's
+  if (jl >= 0 && jl < 4) {
+    const float e1 = row[a.W - 1], e2 = row[a.W - 2];
+    float add;
+    if (a.H & 1) add = dot2(e1, e2, k3, k4);                        // sic: row parity (lpyr_dec.py:206-207)
+    else add = e1 * k4;                                             // :209
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j == jl) h[j] = (a.H & 1) ? h[j] + add : __builtin_fmaf(e1, k4, h[j]);
+    }
+  }
+}
+
+// ANYW = false: W % 8 == 0 (aligned 16-byte accesses, the last output column in slot 3); true: any width >= 16.
+template <bool ANYW>
 __global__ __launch_bounds__(256) void k_reduce_vec(ReduceArgs a) {
   const int img = blockIdx.z;
   const int plane = img / a.n_img, it = img - plane * a.n_img;
@@ -138,8 +182,12 @@ __global__ __launch_bounds__(256) void k_reduce_vec(ReduceArgs a) {
   float w[5][4];
   const bool edge = blockIdx.x == 0 || (blockIdx.x + 1) * 1024 >= a.Wo;     // block-uniform
   auto hrow = [&](int y, float (&h)[4]) {
-    if (edge) hreduce_row<true>(a, in, y, 1.0f, ox, first, last, h);
-    else hreduce_row<false>(a, in, y, 1.0f, ox, false, false, h);
+    if constexpr (ANYW) {
+      hreduce_row_any(a, in, y, ox, h);      // (interior threads take its 16-byte branch: same loads as the aligned kernel)
+    } else {
+      if (edge) hreduce_row<true>(a, in, y, 1.0f, ox, first, last, h);
+      else hreduce_row<false>(a, in, y, 1.0f, ox, false, false, h);
+    }
   };
 #pragma unroll
   for (int k = 0; k < 3; ++k) hrow(2 * oy0 - 2 + k, w[k]);         // rows 2oy-2, 2oy-1, 2oy of the first output
@@ -167,7 +215,13 @@ __global__ __launch_bounds__(256) void k_reduce_vec(ReduceArgs a) {
         for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaf(w[3][j], k4, o[j]);
       }
     }
-    *reinterpret_cast<float4*>(out + (int64_t)oy * a.Wo + ox) = make_float4(o[0], o[1], o[2], o[3]);
+    if constexpr (ANYW) {
+      float* dst = out + (int64_t)oy * a.Wo + ox;
+      if (ox + 4 <= a.Wo) *reinterpret_cast<f4u*>(dst) = f4u{o[0], o[1], o[2], o[3]};
+      else for (int j = 0; j < a.Wo - ox; ++j) dst[j] = o[j];
+    } else {
+      *reinterpret_cast<float4*>(out + (int64_t)oy * a.Wo + ox) = make_float4(o[0], o[1], o[2], o[3]);
+    }
   }
 }
 
@@ -307,7 +361,12 @@ void launch_reduce2(const Reduce2Args& a0, hipStream_t s) {
 void launch_reduce(const ReduceArgs& a, hipStream_t s) {
   if (a.W % 8 == 0 && a.H >= 4) {
     dim3 grid((a.Wo / 4 + 255) / 256, (a.Ho + RSEG - 1) / RSEG, a.n_planes * a.n_img);
-    hipLaunchKernelGGL(k_reduce_vec, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_reduce_vec<false>, grid, dim3(256), 0, s, a);
+    return;
+  }
+  if (a.W >= 16 && a.H >= 4) {             // any other width: the same marching kernel with per-sample border handling
+    dim3 grid(((a.Wo + 3) / 4 + 255) / 256, (a.Ho + RSEG - 1) / RSEG, a.n_planes * a.n_img);
+    hipLaunchKernelGGL(k_reduce_vec<true>, grid, dim3(256), 0, s, a);
     return;
   }
   dim3 grid((a.Wo + RT - 1) / RT, (a.Ho + RT - 1) / RT, a.n_planes * a.n_img);

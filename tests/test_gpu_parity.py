@@ -585,3 +585,31 @@ def test_streaming_heatmap_sink_matches_the_whole_clip_tensor(tmp_path):
     assert png.frames_written == F and (tmp_path / "seq" / ("hm_%03d.png" % (F - 1))).stat().st_size > 500
     with pytest.raises(cv.vq_exception):
         _metric(dict(meta, heatmap=None)).predict_video_source(vs, heatmap_sink=sink)
+
+
+@pytest.mark.parametrize("W", [245, 248, 249, 250, 251, 252, 253, 254, 255, 341, 342, 683])
+def test_ragged_widths_against_oracle(W):
+    """every width takes the marching reduce and the fused band kernel (W % 8 in 1..7, odd and even, the
+    last lane of the last strip holding 1..3 valid columns, one and several strips, odd heights for the row-parity quirk of
+    lpyr_dec.py:206) -- features against the oracle, per-pixel D of every level against the oracle for one of them."""
+    import colorvideovdp_amd as cv
+    from oracle import cvvdp_oracle as orc
+    rng = np.random.default_rng(W)
+    H = 97 if W % 2 else 80
+    F, fps = (3, 30) if W < 300 else (2, 60)
+    y, x = np.mgrid[0:H, 0:W]
+    ref = np.stack([np.stack([0.45 + 0.3 * np.sin(2 * np.pi * (4.3 * x / W + f / 7.0) + c) * np.cos(2 * np.pi * 2.7 * y / H) for c in range(3)])
+                    for f in range(F)], axis=1)[None]
+    test = np.clip(ref + 0.05 * rng.standard_normal(ref.shape), 0, 1)        # noise right up to the right edge
+    test, ref = np.round(test * 255).astype(np.uint8), np.round(np.clip(ref, 0, 1) * 255).astype(np.uint8)
+    o = orc.Oracle(display_name="standard_fhd")
+    ojod, ostats = o.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
+    m = cv.cvvdp(display_name="standard_fhd")
+    jod, stats = m.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
+    assert abs(float(jod) - float(ojod)) <= JOD_TOL
+    np.testing.assert_allclose(stats["Q_per_ch"], ostats["Q_per_ch"], rtol=2e-4, atol=2e-6)
+    # heat map path of the ragged kernels (per-pixel outputs reach the right edge)
+    oh = orc.Oracle(display_name="standard_fhd", heatmap="raw")
+    _, ohs = oh.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
+    _, hs = cv.cvvdp(display_name="standard_fhd", heatmap="raw").predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
+    _check_heatmap(hs["heatmap"], ohs["heatmap"].numpy() if torch.is_tensor(ohs["heatmap"]) else ohs["heatmap"])

@@ -1,0 +1,19 @@
+#!/bin/bash
+# throughput on other shapes (64 frames, u8, resident): tools/shape_bench.sh "1366x768 1360x768 854x480 848x480 ..."
+python - "$@" <<'PY'
+import sys, time, torch
+sys.path.insert(0, ".")
+import bench, colorvideovdp_amd as cv
+dev = torch.device("cuda")
+for shape in (sys.argv[1:] or ["1366x768", "1360x768", "854x480", "848x480", "1920x1080", "2560x1440"]):
+    W, H = (int(v) for v in shape.split("x"))
+    clip = bench.ResidentClip(64, 0, 64, H, W, 60, "u8", dev)
+    m = cv.cvvdp(display_name="standard_fhd")
+    for _ in range(3):
+        m.predict_video_source(clip)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        jod, _ = m.predict_video_source(clip)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    print(f"{shape}: {dt * 1e3:.3f} ms per 64 frames, {W * H * 64 / dt / 1e9:.2f} Gpixel/s, JOD {float(jod):.4f}")
+PY

@@ -1,45 +1,65 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_pmc_fetch_size.txt + <tag>_pmc_write_size.txt -> profiles/traffic_band0.json (read by bench.py).
-FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 counts the 128-byte requests of wide coalesced reads as
-64 B); WRITE_SIZE is used as reported.  Usage: make_traffic_json.py r01"""
+"""profiles/<tag>_pmc_fetch_size.txt + <tag>_pmc_write_size.txt -> profiles/traffic.json (read by bench.py): counter bytes
+against algorithmic bytes for every dominant kernel of the 4K x 64 fp32 step.
+
+FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 counts the 128-byte requests of wide coalesced reads as 64 B);
+WRITE_SIZE is used as reported (calibrated on k_fir_rot, whose reads and writes are exactly its algorithmic bytes).
+Usage: make_traffic_json.py r02"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PIX = 3840 * 2160 * 64
+KERNELS = {
+    # key: (substring of the kernel name, workgroups of the level-0 launch, algorithmic bytes per launch, what they are)
+    "temporal_fir": ("k_fir_rot<3, 17>", None, PIX * (24 + 32.0), "24 B/pixel in (fp32 RGB, test + reference) + 32 B/pixel out (8 level-0 planes)"),
+    "pyr_reduce_l0": ("k_reduce2", None, PIX * (32 + 8 + 2.0), "levels 0 -> 1 -> 2 in one pass: 32 B/pixel in, 8 + 2 B/pixel out"),
+    "band_level0": ("k_band4<4, false, false>", None, PIX * 40.0, "g0 (32 B/pixel) + g1 (8 B/pixel) in; partial sums out"),
+}
 
 
-def level0_row(path, counter):
-    best = None
+def rows(path, counter):
+    out = {}
     for line in open(path):
         f = line.split()
-        if "k_band4<4" in line and counter in f:
+        if counter in f:
             i = f.index(counter)
-            wg, disp, per = int(f[i - 1]), int(f[i + 1]), float(f[i + 3])
-            if best is None or wg > best[0]:
-                best = (wg, disp, per)
+            name = " ".join(f[:i - 1])
+            out.setdefault(name, []).append((int(f[i - 1]), int(f[i + 1]), float(f[i + 3])))
+    return out
+
+
+def biggest(table, sub):
+    best = None
+    for name, lst in table.items():
+        if sub in name:
+            for wg, disp, per in lst:
+                if best is None or wg * per > best[0] * best[2]:
+                    best = (wg, disp, per)
     return best
 
 
 def main(tag):
-    fe = level0_row(os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch_size.txt"), "FETCH_SIZE")
-    wr = level0_row(os.path.join(ROOT, "profiles", f"{tag}_pmc_write_size.txt"), "WRITE_SIZE")
-    algo = 3840 * 2160 * 64 * 40.0
-    out = {
-        "workload": "4k64", "dtype": "f32",
-        "kernel": "k_band4<4> level 0 (3840x2160, 64 frames per launch)",
-        "FETCH_SIZE_KB_per_launch": fe[2], "WRITE_SIZE_KB_per_launch": wr[2],
-        "launches_sampled": [fe[1], wr[1]],
-        "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests of wide coalesced reads as 64 B, "
-                      "MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
-        "hbm_bytes_per_launch": fe[2] * 1024 * 2 + wr[2] * 1024,
-        "algorithmic_bytes_per_launch": algo,
-        "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py "
-                  f"--steps 2 --warmup 1 --no-profile; profiles/{tag}_pmc_*.txt (tools/refresh_profiles.sh)",
-    }
-    json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_band0.json"), "w"), indent=1)
+    fe = rows(os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch_size.txt"), "FETCH_SIZE")
+    wr = rows(os.path.join(ROOT, "profiles", f"{tag}_pmc_write_size.txt"), "WRITE_SIZE")
+    kernels = {}
+    for key, (sub, _, algo, what) in KERNELS.items():
+        f, w = biggest(fe, sub), biggest(wr, sub)
+        if f is None:
+            continue
+        hbm = f[2] * 1024 * 2 + (w[2] * 1024 if w else 0.0)
+        kernels[key] = {"kernel": sub, "workgroups": f[0], "FETCH_SIZE_KB_per_launch": f[2], "WRITE_SIZE_KB_per_launch": w[2] if w else None,
+                        "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": algo, "measured_over_algorithmic": round(hbm / algo, 4),
+                        "algorithmic_bytes": what, "launches_sampled": f[1]}
+    out = {"workload": "4k64", "dtype": "f32", "kernels": kernels,
+           "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests of wide coalesced reads as 64 B, MI355X_MICROARCH.md HBM section); "
+                         "WRITE_SIZE as reported",
+           "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 "
+                     f"--no-profile; profiles/{tag}_pmc_*.txt (tools/refresh_profiles.sh)"}
+    json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r02")

@@ -1,14 +1,15 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on a GPU box (run from the repo root through gpurun):
-#   tools/refresh_profiles.sh r01
-# Writes everything under gpurun_out/refresh/ (merged back by gpurun); copy the *.txt/*.json into profiles/.
+#   tools/refresh_profiles.sh r02
+# Writes everything under gpurun_out/refresh/ (merged back by gpurun); copy the *.txt/*.json into profiles/ and run
+# tools/make_traffic_json.py <tag>.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$(pwd)
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-profile"
+BENCH="python bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-profile --gen gpu"
 summ() { python $R/tools/rocpd_summary.py "$(find $1 -name '*.db' | head -1)"; }
 # 1. kernel trace (timing only)
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- bash -c "cd $R && $BENCH" > $OUT/kt.log 2>&1 )
@@ -19,18 +20,30 @@ for c in FETCH_SIZE WRITE_SIZE; do
   summ $OUT/pmc_$c > $OUT/${TAG}_pmc_$(echo $c | tr A-Z a-z).txt
 done
 rm -rf $OUT/kt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE     # the rocpd databases are large; keep the summaries
-# 3. bench lines
+# 2b. SQ counters of the three dominant kernels
+tools/sq_counters.sh > $OUT/${TAG}_pmc_sq_counters_body.txt 2> $OUT/sq.err
+# 3. bench lines: the default line (BASELINE metric clip, reference-checked), the other configurations, other input formats
 timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 : > $OUT/${TAG}_bench_other_workloads.jsonl
 timeout 900 python bench.py --workload fhd64 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --workload 4k256 --cpu-frames 0 --steps 2 --warmup 1 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
+timeout 900 python bench.py --workload 4k256 --dtype u8 --cpu-frames 0 --steps 2 --warmup 1 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
+timeout 900 python bench.py --workload 4k1024 --cpu-frames 0 --steps 2 --warmup 1 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
+timeout 900 python bench.py --workload 8k256pq --cpu-frames 0 --steps 2 --warmup 1 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --dtype u8 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --dtype yuv420p8 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --dtype yuv420p10 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
-# 3b. heat-map path (configs[4] shape per GPU) and the shard-halo cost
+# 3b. the multi-rank path on this one GPU: 2 ranks over gloo sharing the device (shard plan, halo frames, gather, rank-0 line)
+for w in 4k64 4k1024; do
+  CVVDP_BENCH_BACKEND=gloo CVVDP_BENCH_DEVICE=0 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+    --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --workload $w --steps 2 --warmup 1 --cpu-frames 0 $([ $w = 4k1024 ] && echo --frames 256) \
+    >> $OUT/${TAG}_two_ranks_one_gpu_gloo.log 2>&1
+done
+# 3c. heat-map path (whole-clip tensor), shard-halo cost, other shapes
 timeout 900 python tools/heatmap_bench.py 4k 32 > $OUT/${TAG}_heatmap_bench.txt 2>&1
 timeout 900 python tools/heatmap_bench.py 8k 24 >> $OUT/${TAG}_heatmap_bench.txt 2>&1
 timeout 600 python tools/shard_halo_bench.py > $OUT/${TAG}_shard_halo_bench.txt 2>&1
+timeout 600 tools/shape_bench.sh 2560x1440 1920x1080 1366x768 1360x768 854x480 848x480 > $OUT/${TAG}_shape_bench.txt 2>&1
 # 4. GPU test log
-timeout 900 python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest_gpu.log 2>&1
+timeout 1800 python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest_gpu.log 2>&1
 tail -3 $OUT/${TAG}_pytest_gpu.log; cat $OUT/${TAG}_bench.json

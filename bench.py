@@ -25,6 +25,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The CPU frame generator runs many OpenMP teams; idle OpenMP workers that keep spinning afterwards steal the cores the
+# HIP runtime's launch path needs (measured: kernels queue late and a 19 ms step takes 40 ms).  Must be set before torch loads.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
 
 import numpy as np
 import torch
@@ -85,9 +89,13 @@ class ResidentClip:
         self.ref = torch.empty((1, 3, hi - lo, H, W), dtype=tdt, device=device)
         self.checksum_test = self.checksum_ref = 0
         made = None
-        if gen == "cpu":      # ~1 s per 4K frame on one thread pool: make the frames concurrently (torch releases the GIL)
-            import concurrent.futures
-            pool = concurrent.futures.ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1))
+        if gen == "cpu":      # ~1 s per 4K frame single-threaded: make several frames concurrently (torch releases the GIL),
+            import concurrent.futures          # each with a share of the cores (no nested oversubscription)
+            ncpu = os.cpu_count() or 1
+            workers = max(1, min(8, ncpu // 4))
+            threads_before = torch.get_num_threads()
+            torch.set_num_threads(max(1, min(threads_before, ncpu // workers)))
+            pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers)
             made = pool.map(lambda f: synth_frame(f, H, W, "cpu"), range(lo, hi))
         for f in range(lo, hi):
             t, r = next(made) if made is not None else synth_frame(f, H, W, device)
@@ -101,6 +109,9 @@ class ResidentClip:
                 t, r = t.float() / 255, r.float() / 255
             self.test[0, :, f - lo] = t
             self.ref[0, :, f - lo] = r
+        if made is not None:
+            pool.shutdown(wait=True)
+            torch.set_num_threads(threads_before)
 
     def get_video_size(self):
         return (self.H, self.W, self.n_total)

@@ -182,16 +182,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   // move the window to the row requested last (same odd / fast as its coarse_issue) and write its vertically expanded row to s_ve[buf]
   auto coarse_finish = [&](int buf, auto odd, auto fast) {
     if constexpr (decltype(fast)::value) {
-      if constexpr (!decltype(odd)::value) {
-        // the window moves up in place: twelve register moves (left to the compiler the loop-carried window costs twenty)
-        const float4 nC = replicate(make_float4(cN.x, cN.y, cN.z, cN.w));
-        asm volatile("v_mov_b32 %0, %8\n\tv_mov_b32 %1, %9\n\tv_mov_b32 %2, %10\n\tv_mov_b32 %3, %11\n\t"
-                     "v_mov_b32 %4, %12\n\tv_mov_b32 %5, %13\n\tv_mov_b32 %6, %14\n\tv_mov_b32 %7, %15"
-                     : "+v"(cA.x), "+v"(cA.y), "+v"(cA.z), "+v"(cA.w), "+v"(cB.x), "+v"(cB.y), "+v"(cB.z), "+v"(cB.w)
-                     : "v"(cB.x), "v"(cB.y), "v"(cB.z), "v"(cB.w), "v"(cC.x), "v"(cC.y), "v"(cC.z), "v"(cC.w));
-        asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-                     : "+v"(cC.x), "+v"(cC.y), "+v"(cC.z), "+v"(cC.w) : "v"(nC.x), "v"(nC.y), "v"(nC.z), "v"(nC.w));
-      }
+      if constexpr (!decltype(odd)::value) { cA = cB; cB = cC; cC = replicate(make_float4(cN.x, cN.y, cN.z, cN.w)); }
     } else if (reloaded) {                          // raw rows: once only (a shifted chunk must not be shifted again)
       cA = replicate(cA); cB = replicate(cB); cC = replicate(cC);
     }

@@ -12,7 +12,7 @@ MAX_WINDOW = 256
 CSF_NODES = 32
 PROF_N = 6
 PROF_NAMES = ("photometry", "temporal_fir", "pyr_reduce", "band_level0", "band_rest", "heatmap")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 U8, U16, F16, F32, F32_DKL, YUV8, YUV16 = range(7)
 HEATMAP = {None: 0, "none": 0, "raw": 1, "threshold": 2, "supra-threshold": 3}
@@ -55,6 +55,7 @@ class Clip(C.Structure):
         ("heatmap", C.c_int32),
         ("debug_dump", C.c_int32),
         ("raw_halo", C.c_int32), ("total_frames", C.c_int32),
+        ("feature_size", C.c_int32), ("reserved0", C.c_int32),
         ("taps", C.c_float * (4 * MAX_FILTER_LEN)),
         ("csf_rows", C.c_float * (MAX_LEVELS * 4 * CSF_NODES)),
     ]
@@ -83,6 +84,7 @@ SYMBOLS = {
                                           C.c_int32, C.c_int32, C.c_void_p]),
     "cvvdp_process_block_filtered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                                C.c_int32, C.c_int32, C.c_void_p]),
+    "cvvdp_get_features": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "cvvdp_process_image": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cvvdp_get_q_per_ch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvvdp_pool_jod": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -127,6 +127,11 @@ __global__ __launch_bounds__(BT) void k_band(BandArgs a) {
         const float Tp = ct * S, Rp = cr * S;
         m[c] = fminf(fabsf(Tp), fabsf(Rp));                                 // :845
         d[c] = fabsf(Tp - Rp);
+        if (a.fdump && interior && r >= ys && r < ye) {   // features (cvvdp_ml_metric.py:355): every image pixel once (not the halo columns / rows)
+          const int64_t o = (int64_t)c * a.items_cap * P + (int64_t)item * P + (int64_t)r * W + xcol;
+          a.fdump[o] = fabsf(Tp);
+          a.fdump[(int64_t)4 * a.items_cap * P + o] = fabsf(Rp);
+        }
       }
     } else {
 #pragma unroll
@@ -283,6 +288,10 @@ __global__ __launch_bounds__(256) void k_baseband(BaseArgs a) {
         const float ct = fminf(g[(2 * c) * ps + i] / Lt, 1000.0f);
         const float cr = fminf(g[(2 * c + 1) * ps + i] / Lr, 1000.0f);
         D[c] = fabsf(ct - cr) * S[c];
+        if (a.fdump) {
+          a.fdump[(int64_t)c * ps + (int64_t)item * P + i] = fabsf(ct) * S[c];
+          a.fdump[(int64_t)(4 + c) * ps + (int64_t)item * P + i] = fabsf(cr) * S[c];
+        }
         const float de = D[c] + kEps;
         acc[c] += de * de - kEps * kEps;
         if (a.ddump) a.ddump[(int64_t)c * ps + (int64_t)item * P + i] = D[c];

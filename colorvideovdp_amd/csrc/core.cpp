@@ -18,7 +18,7 @@ namespace {
 struct Level {
   int H = 0, W = 0;
   int64_t P = 0;
-  size_t g_off = 0, heat_off = 0, dd_off = 0;  // float offsets into the workspace
+  size_t g_off = 0, heat_off = 0, dd_off = 0, fd_off = 0;  // float offsets into the workspace
   int n_strip = 1, n_seg = 1, seg_h = 1;
   bool blur = false;
   bool vec4 = false;  // level is handled by k_band4
@@ -206,7 +206,8 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
     a.dchr = heat ? h->ws + lv.heat_off : nullptr;
     heat_weights(h, false, a.hw);
     a.beta_tch = h->p.beta_tch; a.eps_btch = std::pow(kEps, h->p.beta_tch); a.eps_inv_btch = std::pow(kEps, 1.0f / h->p.beta_tch);
-    a.ddump = h->c.debug_dump ? h->ws + lv.dd_off : nullptr;
+    a.ddump = (h->c.debug_dump || h->c.feature_size > 0) ? h->ws + lv.dd_off : nullptr;
+    a.fdump = h->c.feature_size > 0 ? h->ws + lv.fd_off : nullptr;
     if (lv.vec4) launch_band4(a, s);
     else launch_band(a, lv.blur, s);
     FinalizeArgs f{};
@@ -228,7 +229,8 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
     b.dchr = heat ? h->ws + lv.heat_off : nullptr;
     heat_weights(h, true, b.hw);
     b.beta_tch = h->p.beta_tch; b.eps_btch = std::pow(kEps, h->p.beta_tch); b.eps_inv_btch = std::pow(kEps, 1.0f / h->p.beta_tch);
-    b.ddump = h->c.debug_dump ? h->ws + lv.dd_off : nullptr;
+    b.ddump = (h->c.debug_dump || h->c.feature_size > 0) ? h->ws + lv.dd_off : nullptr;
+    b.fdump = h->c.feature_size > 0 ? h->ws + lv.fd_off : nullptr;
     launch_baseband(b, s);
   }
   if (int e = check_launch(h, "baseband")) return e;
@@ -295,6 +297,7 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     if (c.block_frames < 1 || c.filter_len - 1 + c.block_frames > CVVDP_MAX_WINDOW) return fail(h, CVVDP_E_ARG, "block_frames out of range");
   }
   if (c.heatmap != CVVDP_HEATMAP_NONE && c.batch != 1) return fail(h, CVVDP_E_UNSUPPORTED, "heat maps need batch == 1");
+  if (c.feature_size < 0) return fail(h, CVVDP_E_ARG, "feature_size must be >= 0");
   h->c = c;
   h->nch = c.is_video ? 4 : 3;
   h->L = c.n_levels;
@@ -306,7 +309,7 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     Level& lv = h->lv[l];
     lv.H = H; lv.W = W; lv.P = (int64_t)H * W;
     lv.blur = pad > 0 && H > pad && W > pad;
-    lv.vec4 = lv.blur && W >= 16 && H >= 16;   // k_band4 (any width): edge-mirror lanes apart, reflected prefetch rows inside the image
+    lv.vec4 = lv.blur && W >= 16 && H >= 16 && c.feature_size <= 0;   // (features mode: the generic kernel writes |T'|, |R'|)
     const int sw = lv.vec4 ? kBand4StripWidth : (lv.blur ? 256 - 2 * pad : 256);
     lv.n_strip = (W + sw - 1) / sw;
     // Row segments.  Every segment recomputes 12 blur-halo rows, so segments should be long; a block marches ~2.6 us
@@ -347,7 +350,7 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     // off by default: since the kernels were tuned, overlapping the band stage of block k with FIR + reduce of block
     // k+1 no longer gains anything (4K x 256: 84-87 ms either way) and costs a second pyramid set of workspace
     static const bool pipe_env = getenv("CVVDP_PIPELINE") && atoi(getenv("CVVDP_PIPELINE")) != 0;
-    h->pipeline = pipe_env && c.is_video && c.heatmap == CVVDP_HEATMAP_NONE && !c.debug_dump && c.n_frames > c.block_frames;
+    h->pipeline = pipe_env && c.is_video && c.heatmap == CVVDP_HEATMAP_NONE && !c.debug_dump && c.feature_size <= 0 && c.n_frames > c.block_frames;
     const size_t start = off;
     for (auto& lv : h->lv) { lv.g_off = off; off += align_up((size_t)2 * h->nch * h->items_cap * lv.P); }
     h->pyr_set_floats = off - start;
@@ -363,7 +366,8 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     h->hstats_off = off; off += align_up((size_t)h->items_cap * kHeatStatsWords);
     h->hcurve_off = off; off += align_up((size_t)h->items_cap * kHeatCurveWords);
   }
-  if (c.debug_dump) for (auto& lv : h->lv) { lv.dd_off = off; off += align_up((size_t)4 * h->items_cap * lv.P); }
+  if (c.debug_dump || c.feature_size > 0) for (auto& lv : h->lv) { lv.dd_off = off; off += align_up((size_t)4 * h->items_cap * lv.P); }
+  if (c.feature_size > 0) for (auto& lv : h->lv) { lv.fd_off = off; off += align_up((size_t)8 * h->items_cap * lv.P); }
   h->ws_floats = off;
   h->ws = nullptr;
   h->configured = true;
@@ -543,6 +547,23 @@ int cvvdp_process_block_filtered(cvvdp_handle* h, const void* t, const void* r, 
   return run_pyramid_and_bands(h, n_frames, q_frame_offset, s);
 }
 
+int cvvdp_get_features(cvvdp_handle* h, int32_t band, int32_t n_frames, float* dev_out, void* stream) {
+  if (!h || !h->ws) return fail(h, CVVDP_E_STATE, "no workspace bound");
+  if (h->c.feature_size <= 0) return fail(h, CVVDP_E_STATE, "features not enabled (cvvdp_clip.feature_size)");
+  if (band < 0 || band >= h->L) return fail(h, CVVDP_E_ARG, "bad band");
+  if (!dev_out || n_frames < 1 || n_frames * h->c.batch != h->last_items) return fail(h, CVVDP_E_ARG, "n_frames does not match the last block");
+  const Level& lv = h->lv[band];
+  FeatPoolArgs a{};
+  a.tr = h->ws + lv.fd_off; a.d = h->ws + lv.dd_off;
+  a.H = lv.H; a.W = lv.W; a.items = h->last_items; a.items_cap = h->items_cap; a.nch = h->nch; a.fs = h->c.feature_size;
+  a.Hc = (lv.H + a.fs - 1) / a.fs; a.Wc = (lv.W + a.fs - 1) / a.fs;
+  // the band kernels' T', R' carry the channel gain (cvvdp_metric.py:835); the features are |T_f|*S without it (cvvdp_ml_metric.py:355)
+  for (int c = 0; c < 4; ++c) a.inv_gain[c] = band == h->L - 1 ? 1.0f : 1.0f / h->p.ch_gain[c];
+  a.out = dev_out;
+  launch_feature_pool(a, static_cast<hipStream_t>(stream));
+  return check_launch(h, "feature pool");
+}
+
 int cvvdp_process_image(cvvdp_handle* h, void* stream) {
   if (!h || !h->ws) return fail(h, CVVDP_E_STATE, "no workspace bound");
   if (h->c.is_video) return fail(h, CVVDP_E_STATE, "configured for video");
@@ -619,7 +640,7 @@ int cvvdp_debug_buffer(cvvdp_handle* h, int32_t which, int32_t level, void** dev
       *dev_ptr = h->ws + h->hist_off; *n_floats = (size_t)2 * 3 * (fir_kernel_len(h->c.filter_len) - 1) * h->c.batch * h->lv[0].P; break;
     case CVVDP_BUF_GPYR: *dev_ptr = h->ws + lv.g_off; *n_floats = (size_t)2 * h->nch * h->items_cap * lv.P; break;
     case CVVDP_BUF_DDUMP:
-      if (!h->c.debug_dump) return fail(h, CVVDP_E_STATE, "debug_dump not enabled");
+      if (!h->c.debug_dump && h->c.feature_size <= 0) return fail(h, CVVDP_E_STATE, "debug_dump not enabled");
       *dev_ptr = h->ws + lv.dd_off; *n_floats = (size_t)4 * h->items_cap * lv.P; break;
     case CVVDP_BUF_HEAT:
       if (h->c.heatmap == CVVDP_HEATMAP_NONE) return fail(h, CVVDP_E_STATE, "heat map not enabled");

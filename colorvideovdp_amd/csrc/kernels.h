@@ -138,6 +138,7 @@ struct BandArgs {
   float hw[4];       // heat channel weights
   float beta_tch, eps_btch, eps_inv_btch;
   float* ddump;      // debug [4][items_cap][H*W] or null
+  float* fdump;      // features: |T'|, |R'| as [2][4][items_cap][H*W] or null (k_band only)
 };
 void launch_band(const BandArgs& a, bool blur, hipStream_t s);
 void launch_band4(const BandArgs& a, hipStream_t s);   // vectorised variant: W % 8 == 0, blur on, seg_h even
@@ -152,6 +153,7 @@ struct BaseArgs {
   int32_t q_frames, q_levels, q_frame_offset, level, batch;
   float* dchr; float hw[4]; float beta_tch, eps_btch, eps_inv_btch;
   float* ddump;
+  float* fdump;      // features: |T_f|*S, |R_f|*S as [2][4][items_cap][P] or null
 };
 void launch_baseband(const BaseArgs& a, hipStream_t s);
 
@@ -161,6 +163,15 @@ struct FinalizeArgs {
   float* q_out; int32_t q_frames, q_levels, q_frame_offset, level, batch;
 };
 void launch_finalize(const FinalizeArgs& a, hipStream_t s);
+
+struct FeatPoolArgs {        // cvvdp_feature_pooling, cvvdp_ml_metric.py:77-107
+  const float* tr;           // |T'|, |R'|: [2][4][items_cap][P]
+  const float* d;            // D: [4][items_cap][P]
+  int32_t H, W, items, items_cap, nch, fs, Hc, Wc;
+  float inv_gain[4];         // 1 / ch_gain (the kernels' T', R' carry the channel gain, the reference's features do not); 1 for the baseband
+  float* out;                // [items][Hc][Wc][nch][6]
+};
+void launch_feature_pool(const FeatPoolArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- pooling + JOD (K8)
 struct PoolArgs {

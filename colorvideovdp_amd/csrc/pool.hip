@@ -49,4 +49,51 @@ __global__ __launch_bounds__(256) void k_pool(PoolArgs a) {
 
 void launch_pool(const PoolArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_pool, dim3(a.B), dim3(256), 0, s, a); }
 
+// Features for the ML heads: cvvdp_feature_pooling (cvvdp_ml_metric.py:77-107).  One block per (cell, item, channel):
+// mean and E[x^2] - mean^2 of |T'|, |R'| and D over a feature_size x feature_size cell (AvgPool2d with ceil_mode: the last
+// cells of a row / column average over the pixels that exist).  Sums are taken in double in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void k_feature_pool(FeatPoolArgs a) {
+  __shared__ double s_sum[6][4];
+  const int cx = blockIdx.x, cy = blockIdx.y;
+  const int item = blockIdx.z / a.nch, c = blockIdx.z - item * a.nch;
+  const int x0 = cx * a.fs, y0 = cy * a.fs;
+  const int w = min(a.fs, a.W - x0), h = min(a.fs, a.H - y0);
+  const int64_t P = (int64_t)a.H * a.W, ps = (int64_t)a.items_cap * P;
+  const float* T = a.tr + (int64_t)c * ps + (int64_t)item * P;
+  const float* R = T + 4 * ps;
+  const float* D = a.d + (int64_t)c * ps + (int64_t)item * P;
+  const float ig = a.inv_gain[c];
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int e = threadIdx.x; e < w * h; e += 256) {
+    const int yy = e / w, xx = e - yy * w;
+    const int64_t o = (int64_t)(y0 + yy) * a.W + x0 + xx;
+    const float t = T[o] * ig, r = R[o] * ig, d = D[o];
+    acc[0] += t; acc[1] += (double)t * t; acc[2] += r; acc[3] += (double)r * r; acc[4] += d; acc[5] += (double)d * d;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double n = (double)w * h;
+    float* out = a.out + ((((int64_t)item * a.Hc + cy) * a.Wc + cx) * a.nch + c) * 6;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float mean = (float)((s_sum[2 * q][0] + s_sum[2 * q][1] + s_sum[2 * q][2] + s_sum[2 * q][3]) / n);
+      const float msq = (float)((s_sum[2 * q + 1][0] + s_sum[2 * q + 1][1] + s_sum[2 * q + 1][2] + s_sum[2 * q + 1][3]) / n);
+      out[2 * q] = mean;
+      out[2 * q + 1] = msq - mean * mean;         // fp32, like the reference's avg_pool(x**2) - mean**2
+    }
+  }
+}
+
+void launch_feature_pool(const FeatPoolArgs& a, hipStream_t s) {
+  dim3 grid(a.Wc, a.Hc, a.items * a.nch);
+  hipLaunchKernelGGL(k_feature_pool, grid, dim3(256), 0, s, a);
+}
+
 }  // namespace cvvdp

@@ -237,6 +237,24 @@ class cvvdp(vq_metric):
                 self._make_handle()
         return self._predict_video_source(vid_source, height, width, N_frames, is_image, heatmap_sink)
 
+    def extract_features(self, vid_source):
+        """Features for the ML heads (cvvdp_ml_base.extract_features, cvvdp_ml_metric.py:193-277): per band the
+        pooled statistics (mean_T, var_T, mean_R, var_R, mean_D, var_D) of |T_f|*S, |R_f|*S and D over cells of
+        ceil(pix_per_deg) pixels.  Returns (features, heatmap): features[band] is a float32 device tensor
+        [B, F, H', W', channels, 6]; heatmap is None (the ML metrics produce none, :117-118)."""
+        if self.do_heatmap:
+            raise vq_exception("Currently cvvdp-ml metrics do not produce heatmaps")
+        height, width, N_frames = vid_source.get_video_size()
+        self._feature_out = []
+        try:
+            self._score_range(vid_source, 0, N_frames)
+            feats = self._feature_out
+        finally:
+            self._feature_out = None
+        B = vid_source.get_batch_size()
+        # [F*B, H', W', C, 6] (item = frame * B + batch) -> [B, F, H', W', C, 6]
+        return [f.view((N_frames, B) + tuple(f.shape[1:])).transpose(0, 1).contiguous() for f in feats], None
+
     @staticmethod
     def _is_raw_source(vs):
         return hasattr(vs, "get_raw_yuv_block") or hasattr(vs, "get_raw_block") or isinstance(vs, video_source_array)
@@ -377,7 +395,7 @@ class cvvdp(vq_metric):
         # The clip description (temporal taps, CSF rows per band, block size) depends only on the geometry: repeated
         # calls on clips of the same shape reuse it, so the first kernel is not held back by ~0.4 ms of host set-up.
         key = (height, width, N_total, first, count, B, C, is_image, None if is_image else float(vs.get_frames_per_second()), self.heatmap,
-               bool(self.debug_dump), self.block_frames, self.gpu_mem, float(self.pix_per_deg), self._cfg_version, prefiltered,
+               bool(self.debug_dump), self.block_frames, self.gpu_mem, float(self.pix_per_deg), self._cfg_version, prefiltered, getattr(self, "_feature_out", None) is not None,
                self._host_resident(vs))
         cached = getattr(self, "_clip_cache", None)
         if cached is not None and cached[0] == key:
@@ -392,6 +410,7 @@ class cvvdp(vq_metric):
             clip.total_frames = N_total
             clip.heatmap = _capi.HEATMAP[self.heatmap]
             clip.debug_dump = int(self.debug_dump)
+            clip.feature_size = int(math.ceil(self.pix_per_deg)) if getattr(self, "_feature_out", None) is not None else 0   # cvvdp_ml_metric.py:353
             # device-resident clips: later blocks re-read their fl-1 predecessor frames (like a shard's halo) instead of
             # a DKL tail written by the previous block: 3.2 GB less HBM traffic per 64-frame 4K block
             clip.raw_halo = int(not is_image and not self._host_resident(vs) and (is_yuv or isinstance(vs, video_source_array) or hasattr(vs, "get_raw_block")))
@@ -488,6 +507,20 @@ class cvvdp(vq_metric):
                         heatmap[0, ch, ff:ff + n].copy_(buf[ch], non_blocking=True)
                 buf.record_stream(copy_stream)
 
+        feat_out = getattr(self, "_feature_out", None)
+        if feat_out is not None:
+            fs = int(clip.feature_size)
+            lvl = [(height, width)]
+            for _ in range(L - 1):
+                lvl.append(((lvl[-1][0] + 1) // 2, (lvl[-1][1] + 1) // 2))
+            feat_out[:] = [torch.empty((count * B, (h + fs - 1) // fs, (w + fs - 1) // fs, nch, 6), dtype=torch.float32, device=self.device)
+                           for h, w in lvl]
+
+        def fetch_features(ff, n):
+            for bb in range(L):
+                dst = feat_out[bb][ff * B:(ff + n) * B]
+                _capi.check(self._handle, lib.cvvdp_get_features(self._handle, bb, n, dst.data_ptr(), stream), "cvvdp_get_features")
+
         if is_image:
             st, sr = self._strides(probe_t, probe_r)
             rc = lib.cvvdp_put_image(self._handle, probe_t.data_ptr(), probe_r.data_ptr(), code, st, sr, stream)
@@ -495,6 +528,8 @@ class cvvdp(vq_metric):
             _capi.check(self._handle, lib.cvvdp_process_image(self._handle, stream), "cvvdp_process_image")
             if self.do_heatmap:
                 fetch_heatmap(0, 1)
+            if feat_out is not None:
+                fetch_features(0, 1)
         else:
             nb = clip.block_frames
 
@@ -517,6 +552,8 @@ class cvvdp(vq_metric):
                     _capi.check(self._handle, rc, "cvvdp_process_block_filtered")
                     if self.do_heatmap:
                         fetch_heatmap(ff - first, n)
+                    if feat_out is not None:
+                        fetch_features(ff - first, n)
                     del t, r
             blocks = []
             for ff in (range(first, first + count, nb) if not prefiltered else ()):
@@ -583,6 +620,8 @@ class cvvdp(vq_metric):
                         _capi.check(self._handle, rc, "cvvdp_process_block")
                     if self.do_heatmap:
                         fetch_heatmap(ff - first, n)
+                    if feat_out is not None:
+                        fetch_features(ff - first, n)
                     del t, r  # stream-ordered: safe to release to the caching allocator once the kernels are queued
             finally:
                 if prefetch:

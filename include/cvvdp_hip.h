@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CVVDP_ABI_VERSION 6
+#define CVVDP_ABI_VERSION 7
 #define CVVDP_MAX_FILTER_LEN 65 /* 0.25 s at up to 256 fps, cvvdp_metric.py:1059 */
 #define CVVDP_MAX_LEVELS 16
 #define CVVDP_MAX_WINDOW 256    /* filter_len - 1 + frames per block */
@@ -102,6 +102,9 @@ typedef struct cvvdp_clip {
                                    so no DKL tail is kept between blocks; 0: later blocks read the tail (hist_src < 0) */
   int32_t total_frames;         /* frames of the whole clip (all shards); 0 = unknown.  Sizes the band kernels' row segments:
                                    the same for every block and shard of a clip, so results stay bit-identical */
+  int32_t feature_size;         /* > 0: also keep |T'|, |R'| and D of every band for cvvdp_get_features, pooled over
+                                   feature_size x feature_size cells (ceil(pix_per_deg), cvvdp_ml_metric.py:351-355); 0: off */
+  int32_t reserved0;
   float taps[4 * CVVDP_MAX_FILTER_LEN];                             /* F[c][k], not flipped */
   float csf_rows[CVVDP_MAX_LEVELS * 4 * CVVDP_CSF_NODES];           /* [band][ch][node] log10 S */
 } cvvdp_clip;
@@ -171,6 +174,13 @@ int cvvdp_process_block_yuv(cvvdp_handle* h, const void* dev_test, const void* d
 int cvvdp_process_block_filtered(cvvdp_handle* h, const void* dev_test, const void* dev_ref,
                                  const int64_t strides_test[5], const int64_t strides_ref[5], int32_t n_frames,
                                  int32_t q_frame_offset, void* stream);
+
+/* Features for the ML heads: cvvdp_feature_pooling of |T_f|*S, |R_f|*S and D (cvvdp_ml_metric.py:77-107 called
+ * at :355-358) for one band of the block processed last: mean and variance (E[x^2] - mean^2) over feature_size x
+ * feature_size cells, the last cells of a row / column averaging over the pixels that exist (AvgPool2d, ceil_mode).
+ * dev_out: fp32 [n_frames * B][ceil(H_band / fs)][ceil(W_band / fs)][C][6] (mean_T, var_T, mean_R, var_R, mean_D, var_D),
+ * item index = frame * B + batch.  The clip must have been configured with feature_size > 0. */
+int cvvdp_get_features(cvvdp_handle* h, int32_t band, int32_t n_frames, float* dev_out, void* stream);
 
 /* Image variant: pyramid, CSF, masking, pooling of the planes written by cvvdp_put_image. */
 int cvvdp_process_image(cvvdp_handle* h, void* stream);

@@ -22,7 +22,7 @@ def _names(pattern):
 
 def golden_cases():
     """Array-input cases made by oracle/make_goldens.py."""
-    return [n for n in _names("*.npz") if n != "setup" and not n.startswith(("yuv", "fullsize", "kat_", "bench_", "outputs"))]
+    return [n for n in _names("*.npz") if n != "setup" and not n.startswith(("yuv", "fullsize", "kat_", "bench_", "outputs", "features"))]
 
 
 def yuv_cases():

@@ -613,3 +613,33 @@ def test_ragged_widths_against_oracle(W):
     _, ohs = oh.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
     _, hs = cv.cvvdp(display_name="standard_fhd", heatmap="raw").predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
     _check_heatmap(hs["heatmap"], ohs["heatmap"].numpy() if torch.is_tensor(ohs["heatmap"]) else ohs["heatmap"])
+
+
+def test_ml_head_features_against_reference():
+    """cvvdp.extract_features() = the pooled |T_f|*S, |R_f|*S, D statistics the reference's ML heads consume
+    (cvvdp_ml_metric.py:77-107, :302-390), against the real reference (oracle/make_goldens_features.py), video and image."""
+    gf = load_golden("features")
+    k = 0
+    while f"case{k}" in gf:
+        g = load_golden(str(gf[f"case{k}"]))
+        meta = dict(g["meta"], heatmap=None)
+        import colorvideovdp_amd as cv
+        m = _metric(meta, block_frames=7)
+        t, r = _inputs(g)
+        vs = cv.video_source_array(t, r, meta["fps"], dim_order=meta["dim_order"], display_photometry=m.display_photometry)
+        feats, hm = m.extract_features(vs)
+        assert hm is None and len(feats) == int(gf[f"case{k}_bands"])
+        for bb, f in enumerate(feats):
+            want = gf[f"case{k}_band{bb}"]
+            got = f.cpu().numpy()
+            assert got.shape == want.shape, (bb, got.shape, want.shape)
+            # means to the usual feature tolerance; a variance E[x^2] - mean^2 inherits the rounding of both terms
+            for q in (0, 2, 4):
+                np.testing.assert_allclose(got[..., q], want[..., q], rtol=5e-4, atol=2e-6, err_msg=f"band {bb} mean {q}")
+                scale = np.abs(want[..., q]) ** 2 + np.abs(want[..., q + 1])
+                assert np.all(np.abs(got[..., q + 1] - want[..., q + 1]) <= 2e-3 * scale + 1e-7), f"band {bb} var {q + 1}"
+        # the normal path still works on the same object afterwards (features mode is per call)
+        jod, stats = m.predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+        np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
+        k += 1
+    assert k == 2

@@ -250,6 +250,14 @@ def main():
     def step():
         return m.predict_video_source(clip, heatmap_sink=sink) if sink is not None else m.predict_video_source(clip)
 
+    # The GPU has been idle while the clip was made (tens of seconds with the CPU generator) and sits in a low-power state: its
+    # shader clock takes a few hundred milliseconds of load to come back up, far longer than W warm-up steps of 19 ms.  Measured
+    # on a fresh box: the VALU-bound kernels ran 1.6-2x slower through the first ~7 steps.  So the device is first kept busy for
+    # about a second (untimed, like the warm-up steps that follow).
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < float(os.environ.get("CVVDP_BENCH_SPINUP_S", "1.0")):
+        step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         jod, stats = step()
     torch.cuda.synchronize()

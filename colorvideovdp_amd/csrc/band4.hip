@@ -95,7 +95,10 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   // reflect padding overwrites (s_m) or that is masked out (pooling, stores).  Everything ragged sits behind block-uniform
   // branches: full strips and W % 4 == 0 run the same instructions as before.
   // RAGGED is a separate instantiation (launch_band4 picks it when W % 8 != 0): the aligned kernel keeps its register budget.
-  const bool ragged_blk = RAGGED && (W & 3) != 0 && x0 + B4_SW >= W;
+  // (the strip BEFORE the last one sees the right edge too when the last strip is narrower than the halo: its halo lanes then
+  // hold the partial lane and need the mirrored columns)
+  const bool edge_r = x0 + B4_SW + B4_HALO > W;      // block-uniform: this strip's columns x0-8 .. x0+247 reach past column W-1
+  const bool ragged_blk = RAGGED && (W & 3) != 0 && edge_r;
   const int g_shift = RAGGED && in_img ? max(fc0 - (W - 4), 0) : 0;      // 1..3 in the partial lane: loaded element i+g_shift is column fc0+i
   const int n_valid = RAGGED ? (in_img ? min(W - fc0, 4) : 0) : 4;
   const bool interior = j >= 2 && j < 62 && fc0 < W;  // columns whose result is pooled
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
 
   // image-edge mirror roles (see the contrast stage): left edge = lanes with fc0 = 0 / 4 (strip 0), right edge = lanes
   // with fc0 = W-8 / W-4 (last strip); W >= 16 keeps them apart
-  const bool mir_block = strip == 0 || x0 + B4_SW >= W;
+  const bool mir_block = strip == 0 || edge_r;
   const bool mir_any = RAGGED && (W & 3) != 0;       // right edge not on a lane boundary: per-column mirror writes
   int mir_kind = 0, mir_base = 0;
   if (strip == 0 && (fc0 == 0 || fc0 == 4)) { mir_kind = fc0 == 0 ? 1 : 2; mir_base = B4_HALO - (fc0 == 0 ? 1 : 4); }

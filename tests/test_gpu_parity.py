@@ -587,7 +587,7 @@ def test_streaming_heatmap_sink_matches_the_whole_clip_tensor(tmp_path):
         _metric(dict(meta, heatmap=None)).predict_video_source(vs, heatmap_sink=sink)
 
 
-@pytest.mark.parametrize("W", [245, 248, 249, 250, 251, 252, 253, 254, 255, 341, 342, 683])
+@pytest.mark.parametrize("W", [241, 242, 243, 244, 245, 246, 247, 248, 249, 250, 251, 252, 253, 254, 255, 341, 342, 483, 484, 683])
 def test_ragged_widths_against_oracle(W):
     """every width takes the marching reduce and the fused band kernel (W % 8 in 1..7, odd and even, the
     last lane of the last strip holding 1..3 valid columns, one and several strips, odd heights for the row-parity quirk of

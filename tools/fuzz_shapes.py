@@ -1,0 +1,43 @@
+"""Randomised shape sweep of the HIP path against the CPU oracle (development aid, run on the GPU box):
+    python tools/fuzz_shapes.py [n_cases] [seed]
+Random widths / heights (16..700 x 16..400, all residues mod 16), frame counts, frame rates, displays, padding and heat-map modes."""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+import colorvideovdp_amd as cv
+from oracle import cvvdp_oracle as orc
+
+n, seed = (int(sys.argv[1]) if len(sys.argv) > 1 else 30), (int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+rng = np.random.default_rng(seed)
+bad = 0
+for k in range(n):
+    W, H = int(rng.integers(16, 700)), int(rng.integers(16, 400))
+    F = int(rng.choice([1, 1, 2, 3, 7]))
+    fps = 0 if F == 1 else int(rng.choice([24, 30, 60]))
+    disp = str(rng.choice(["standard_fhd", "standard_4k", "standard_hdr_pq"]))
+    pad = str(rng.choice(["replicate", "symmetric"]))
+    heat = str(rng.choice(["none", "none", "raw", "threshold", "supra-threshold"]))
+    heat = None if heat == "none" else heat
+    y, x = np.mgrid[0:H, 0:W]
+    ref = np.stack([np.stack([0.45 + 0.3 * np.sin(2 * np.pi * (3.1 * x / W + f / 9.0) + c) * np.cos(2 * np.pi * 2.3 * y / H) for c in range(3)])
+                    for f in range(F)], axis=1)[None]
+    test = np.clip(ref + 0.05 * rng.standard_normal(ref.shape), 0, 1)
+    test, ref = np.round(test * 255).astype(np.uint8), np.round(np.clip(ref, 0, 1) * 255).astype(np.uint8)
+    o = orc.Oracle(display_name=disp, temp_padding=pad, heatmap=heat)
+    oj, os_ = o.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
+    m = cv.cvvdp(display_name=disp, temp_padding=pad, heatmap=heat, block_frames=int(rng.choice([1, 2, 64])))
+    j, s = m.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
+    dq = np.abs(s["Q_per_ch"] - os_["Q_per_ch"]) / (np.abs(os_["Q_per_ch"]) * 2e-4 + 2e-6)
+    msg = f"{k:3d} {W}x{H}x{F} fps {fps} {disp} {pad} heat {heat}: dJOD {abs(float(j) - float(oj)):.2e}  Q err/tol {dq.max():.2f}"
+    ok = abs(float(j) - float(oj)) <= 1e-3 and dq.max() <= 1.0
+    if heat:
+        a = s["heatmap"].numpy().astype(np.float32)
+        b = os_["heatmap"]
+        b = (b.numpy() if torch.is_tensor(b) else b).astype(np.float32)
+        d = np.abs(a - b)
+        msg += f"  heat frac>2e-3 {(d > 2e-3).mean():.1e} max {d.max():.1e}"
+        ok = ok and (d > 2e-3).mean() < 1e-3 and d.max() < 2e-2
+    print(("ok  " if ok else "BAD ") + msg, flush=True)
+    bad += not ok
+print("bad:", bad)

@@ -1,6 +1,6 @@
-"""`python -m colorvideovdp_amd ...` = the `cvvdp` command line (colorvideovdp_amd/run_cvvdp.py)."""
+"""`python -m colorvideovdp_amd ...` = the `cvvdp` command line (colorvideovdp_amd/cli.py)."""
 import sys
 
-from .run_cvvdp import main
+from .cli import main
 
 sys.exit(main())

@@ -1,4 +1,4 @@
-"""Command line of the MI355X build: `python -m colorvideovdp_amd` / `cvvdp` (console entry in setup.py).
+"""Command line of the MI355X build: `python -m colorvideovdp_amd` / `cvvdp` (console entry in pyproject.toml).
 
 Mirrors the reference's command line (pycvvdp/run_cvvdp.py:83-118 arguments, :120-371 run_on_args) for the path this build
 implements: the `cvvdp` metric on image pairs (PNG / JPEG / anything Pillow reads, 8 or 16 bit), planar .yuv clips (the
@@ -43,37 +43,45 @@ def expand_wildcards(filestrs):
     return files
 
 
+# The reference's options (run_cvvdp.py:83-118): (flags, argparse keywords).  Kept as data: the names, defaults and arities are
+# the contract existing scripts rely on; the help texts say what THIS build does with them.
+_NA = "not available in this build"
+_OPTIONS = (
+    (("-t", "--test"), dict(type=str, nargs="+", help="test images / clips (wildcards allowed)")),
+    (("-r", "--ref"), dict(type=str, nargs="+", help="reference images / clips; one reference may serve many tests and vice versa")),
+    (("--device",), dict(type=str, default="cuda", help="'cuda' or 'cuda:N' (there is no CPU path)")),
+    (("--heatmap",), dict(type=str, default="none", help="difference map: none, raw, threshold or supra-threshold")),
+    (("-g", "--distogram"), dict(type=float, default=-1, const=10, nargs="?", help="write a distogram; optional value = JOD at the top of the colour scale")),
+    (("-x", "--features"), dict(action="store_true", default=False, help="write the per-band features as JSON")),
+    (("-o", "--output-dir"), dict(type=str, default=None, help="where heat maps, distograms and feature files go (default: here)")),
+    (("--result",), dict(type=str, default=None, help="CSV file for the predictions")),
+    (("-c", "--config-paths"), dict(type=str, nargs="+", default=[], help="extra configuration files / directories (display_models.json, ...)")),
+    (("-d", "--display"), dict(type=str, default="standard_4k", help="display model name; ? lists them")),
+    (("-n", "--nframes"), dict(type=int, default=-1, help="use only the first N frames")),
+    (("--count-frames",), dict(action="store_true", default=False, help="accepted for compatibility (frame counts of .yuv / .npy inputs are exact)")),
+    (("-f", "--full-screen-resize"), dict(choices=["bilinear", "bicubic", "nearest", "area"], default=None, help=_NA)),
+    (("-m", "--metric"), dict(nargs="+", default=["cvvdp"], help="metric(s); this build registers cvvdp")),
+    (("--temp-padding",), dict(choices=["replicate", "symmetric", "valid"], default="symmetric", help="padding before the first frame ('valid': " + _NA + ")")),
+    (("--pix-per-deg",), dict(type=float, default=None, help="override the display geometry")),
+    (("--fps",), dict(type=float, default=None, help="frame rate: needed for .npy clips, overrides a .yuv file name")),
+    (("--frames",), dict(type=str, default=None, help=_NA)),
+    (("--gpu-mem",), dict(type=float, default=None, help="GPU memory budget in GB")),
+    (("-q", "--quiet"), dict(action="store_true", default=False, help="print the JOD value only")),
+    (("-v", "--verbose"), dict(action="store_true", default=False, help="more log output")),
+    (("--debug",), dict(action="store_true", default=False, help="stack traces for errors")),
+    (("--ffmpeg-cc",), dict(action="store_true", default=False, help="accepted for compatibility, no effect")),
+    (("--temp-resample",), dict(type=float, nargs="?", default=-1, const=0, help=_NA)),
+    (("-i", "--interactive"), dict(action="store_true", default=False, help="one command line per line of standard input")),
+    (("--dump-channels",), dict(nargs="+", choices=["temporal", "lpyr", "difference"], default=None, help=_NA)),
+)
+
+
 def parse_args(arg_list=None):
-    """The reference's options (run_cvvdp.py:83-118); unsupported ones are accepted and refused with a message."""
-    available = [mm.replace("_", "-") for mm in vq_metric_dict.keys()]
-    p = argparse.ArgumentParser(prog="cvvdp", description="Evaluate ColorVideoVDP on a set of images / videos (MI355X build)")
-    p.add_argument("-t", "--test", type=str, nargs="+", required=False, help="list of test images/videos")
-    p.add_argument("-r", "--ref", type=str, nargs="+", required=False, help="list of reference images/videos")
-    p.add_argument("--device", type=str, default="cuda", help="PyTorch device: 'cuda', 'cuda:0', ... (this build has no CPU path)")
-    p.add_argument("--heatmap", type=str, default="none", help="type of difference map (none, raw, threshold, supra-threshold).")
-    p.add_argument("-g", "--distogram", type=float, default=-1, const=10, nargs="?",
-                   help="generate a distogram; the optional value is the maximum JOD of the colour scale")
-    p.add_argument("-x", "--features", action="store_true", default=False, help="generate JSON files with extracted features")
-    p.add_argument("-o", "--output-dir", type=str, default=None, help="directory for heat maps, distograms and feature files")
-    p.add_argument("--result", type=str, default=None, help="write the predictions to this CSV file")
-    p.add_argument("-c", "--config-paths", type=str, nargs="+", default=[], help="paths to configuration files or directories")
-    p.add_argument("-d", "--display", type=str, default="standard_4k", help="display name, or ? to print the list of models")
-    p.add_argument("-n", "--nframes", type=int, default=-1, help="the number of video frames to compare")
-    p.add_argument("--count-frames", action="store_true", default=False, help="(accepted; frame counts of .yuv / .npy inputs are exact)")
-    p.add_argument("-f", "--full-screen-resize", choices=["bilinear", "bicubic", "nearest", "area"], default=None, help="not available in this build")
-    p.add_argument("-m", "--metric", choices=available, nargs="+", default=["cvvdp"], help="metric(s) to run (this build: cvvdp)")
-    p.add_argument("--temp-padding", choices=["replicate", "symmetric", "valid"], default="symmetric", help="temporal padding of the first frames")
-    p.add_argument("--pix-per-deg", type=float, default=None, help="overwrite the display geometry with this pixels-per-degree value")
-    p.add_argument("--fps", type=float, default=None, help="frames per second (required for .npy videos; overrides the .yuv file name)")
-    p.add_argument("--frames", type=str, default=None, help="not available in this build (frame ranges of image sequences)")
-    p.add_argument("--gpu-mem", type=float, default=None, help="how much GPU memory may be used, in GB")
-    p.add_argument("-q", "--quiet", action="store_true", default=False, help="print only the final JOD value")
-    p.add_argument("-v", "--verbose", action="store_true", default=False, help="print extra information")
-    p.add_argument("--debug", action="store_true", default=False, help="print the stack trace of errors")
-    p.add_argument("--ffmpeg-cc", action="store_true", default=False, help="(accepted, no effect)")
-    p.add_argument("--temp-resample", type=float, nargs="?", default=-1, const=0, help="not available in this build")
-    p.add_argument("-i", "--interactive", action="store_true", default=False, help="read command lines from the standard input, one per line")
-    p.add_argument("--dump-channels", nargs="+", choices=["temporal", "lpyr", "difference"], default=None, help="not available in this build")
+    p = argparse.ArgumentParser(prog="cvvdp", description="ColorVideoVDP on MI355X: quality of test images / videos against their references")
+    for flags, kw in _OPTIONS:
+        if flags[-1] == "--metric":
+            kw = dict(kw, choices=[mm.replace("_", "-") for mm in vq_metric_dict.keys()])
+        p.add_argument(*flags, **kw)
     return p.parse_args(arg_list)
 
 

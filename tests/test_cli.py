@@ -1,4 +1,4 @@
-"""The `cvvdp` command line (colorvideovdp_amd/run_cvvdp.py) against the reference's command-line contract
+"""The `cvvdp` command line (colorvideovdp_amd/cli.py) against the reference's command-line contract
 (pycvvdp/run_cvvdp.py:83-371): options, output lines, CSV / JSON / PNG side outputs, on committed fixtures."""
 import json
 import os
@@ -19,7 +19,7 @@ def _write_yuv(g, d):
 
 
 def test_arguments_mirror_the_reference():
-    from colorvideovdp_amd import run_cvvdp as rc
+    from colorvideovdp_amd import cli as rc
     a = rc.parse_args(["--test", "a.png", "--ref", "b.png"])
     # run_cvvdp.py:88-117 defaults
     assert (a.device, a.heatmap, a.distogram, a.features, a.display, a.nframes, a.metric, a.temp_padding, a.quiet, a.interactive) == \
@@ -31,7 +31,7 @@ def test_arguments_mirror_the_reference():
 
 
 def test_refusals_need_no_gpu(tmp_path, capsys):
-    from colorvideovdp_amd import run_cvvdp as rc
+    from colorvideovdp_amd import cli as rc
     for extra in (["--device", "cpu"], ["--temp-padding", "valid"], ["--temp-resample"], ["--full-screen-resize", "bilinear"]):
         assert rc.main(["-t", "a.png", "-r", "b.png"] + extra) == 1          # vq_exception -> logged, exit code 1
     assert rc.main([]) == 0                                                   # "Paths to both ... need to be specified", like the reference
@@ -45,7 +45,7 @@ def test_refusals_need_no_gpu(tmp_path, capsys):
 
 @pytest.mark.gpu
 def test_yuv_pair_with_all_side_outputs(tmp_path, capsys):
-    from colorvideovdp_amd import run_cvvdp as rc
+    from colorvideovdp_amd import cli as rc
     g = load_golden("yuv420_8b_709_64x48x10_30")
     ft, fr = _write_yuv(g, str(tmp_path))
     out = tmp_path / "out"
@@ -73,7 +73,7 @@ def test_yuv_pair_with_all_side_outputs(tmp_path, capsys):
 def test_image_pairs_quiet_and_interactive(tmp_path, capsys, monkeypatch):
     import io
     from PIL import Image
-    from colorvideovdp_amd import run_cvvdp as rc
+    from colorvideovdp_amd import cli as rc
     g = load_golden("img_u8_64x96_fhd_thr")             # an image case with a threshold heat map from the reference
     meta = g["meta"]
     assert meta["dim_order"] == "HWC" and meta["heatmap"] == "threshold"

@@ -57,7 +57,7 @@ __device__ __forceinline__ int refl(int i, int n) {
   return i;
 }
 
-template <int NCH, bool HEAT, bool RAGGED>
+template <int NCH, bool HEAT, bool RAGGED, bool DUMP>
 __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   constexpr int NP = 2 * NCH;
   // s_ve is a ring of two rows (row parity): row r+1 is written during phase 1 of row r, so that phase 2 can derive
@@ -124,7 +124,8 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   }
   for (int i = t; i < 2 * NP * (B4_VE / 2); i += 64 * NCH) (&s_ve[0][0][0])[i] = make_float2(0.0f, 0.0f);   // unwritten apron elements
   __syncthreads();
-  const float e0 = a.kx[0], e1 = a.kx[1], eo = a.kx[2];
+  float e0 = a.kx[0], e1 = a.kx[1], eo = a.kx[2];
+  float mask_p = a.mask_p, eps_p = a.eps_p;
   // lpyr_dec.py:408, interp.py:93 in the log2 domain: ind = (log10 L - first) * scale = log2 L * ind_k1 - ind_k0 (host constants)
   // Wave-uniform constants that are used as plain VALU operands are parked in VGPRs (the empty asm hides their uniformity):
   // the loop needs ~110 SGPRs (13 + 14 blur taps, row arithmetic, exec masks), and every SGPR spilled to a VGPR lane
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   float inv_dmax = a.inv_dmax;
   if constexpr (!RAGGED) {   // (the ragged instantiation is short of VGPRs instead)
     B4_IN_VGPR(ind_k0); B4_IN_VGPR(xw1); B4_IN_VGPR(xw2); B4_IN_VGPR(xw3); B4_IN_VGPR(m1c); B4_IN_VGPR(inv_dmax);
+    B4_IN_VGPR(e0); B4_IN_VGPR(e1); B4_IN_VGPR(eo); B4_IN_VGPR(mask_p); B4_IN_VGPR(eps_p);
   }
 #undef B4_IN_VGPR
 
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
       // 1 + M, M = sum_k xw[k][c] * ((blur_k*10^mask_c + eps)^q_k - eps^q_k)     (cvvdp_metric.py:758-760, :849)
       const float M1 = q3.v[i] * xw3 + (q2.v[i] * xw2 + (q1.v[i] * xw1 + (q0.v[i] * xw0 + m1c)));
       // Du = X/(1+M); D = dmax*Du/(dmax+Du) = X / ((1+M) + X/dmax): one reciprocal (:855-856, :949-950)
-      const float X = fast_pow(d.v[i], a.mask_p) - a.eps_p;      // s_d holds |T'-R'| + eps
+      const float X = fast_pow(d.v[i], mask_p) - eps_p;          // s_d holds |T'-R'| + eps
       D[i] = X * fast_rcp(X * inv_dmax + M1);
     }
     if (ragged_blk) {                                              // columns right of the image do not exist
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc += D[i] * (D[i] + 2.0f * kEps);   // (D+eps)^2 - eps^2
-    if (a.ddump) {
+    if constexpr (DUMP) {                                           // per-pixel D for tests / features (its own instantiation)
       float* dd = a.ddump + (int64_t)c * a.items_cap * P + (int64_t)item * P + (int64_t)y * W + fc0;
       if (n_valid == 4) *reinterpret_cast<f4u*>(dd) = f4u{D[0], D[1], D[2], D[3]};
       else for (int i = 0; i < n_valid; ++i) dd[i] = D[i];
@@ -553,12 +555,20 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
 template <bool RAGGED>
 static void launch_band4_w(const BandArgs& a, hipStream_t s) {
   dim3 grid(8 * a.per_xcd);
-  if (a.dchr) {
-    if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, true, RAGGED>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_band4<3, true, RAGGED>), grid, dim3(192), 0, s, a);
+  if (a.dchr) {          // heat map (with or without the per-pixel dump)
+    if (a.ddump) {
+      if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, true, RAGGED, true>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k_band4<3, true, RAGGED, true>), grid, dim3(192), 0, s, a);
+    } else {
+      if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, true, RAGGED, false>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k_band4<3, true, RAGGED, false>), grid, dim3(192), 0, s, a);
+    }
+  } else if (a.ddump) {
+    if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, false, RAGGED, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_band4<3, false, RAGGED, true>), grid, dim3(192), 0, s, a);
   } else {
-    if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, false, RAGGED>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_band4<3, false, RAGGED>), grid, dim3(192), 0, s, a);
+    if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, false, RAGGED, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_band4<3, false, RAGGED, false>), grid, dim3(192), 0, s, a);
   }
 }
 

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   if constexpr (!RAGGED) {   // (the ragged instantiation is short of VGPRs instead)
     B4_IN_VGPR(ind_k0); B4_IN_VGPR(xw1); B4_IN_VGPR(xw2); B4_IN_VGPR(xw3); B4_IN_VGPR(m1c); B4_IN_VGPR(inv_dmax);
     B4_IN_VGPR(e0); B4_IN_VGPR(e1); B4_IN_VGPR(eo); B4_IN_VGPR(mask_p); B4_IN_VGPR(eps_p);
+    B4_IN_VGPR(qc); B4_IN_VGPR(ind_k1); B4_IN_VGPR(xw0);
   }
 #undef B4_IN_VGPR
 

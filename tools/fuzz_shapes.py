@@ -14,7 +14,7 @@ bad = 0
 for k in range(n):
     W, H = int(rng.integers(16, 700)), int(rng.integers(16, 400))
     F = int(rng.choice([1, 1, 2, 3, 7]))
-    fps = 0 if F == 1 else int(rng.choice([24, 30, 60]))
+    fps = 0 if F == 1 else int(rng.choice([24, 30, 50, 60, 120]))
     disp = str(rng.choice(["standard_fhd", "standard_4k", "standard_hdr_pq"]))
     pad = str(rng.choice(["replicate", "symmetric"]))
     heat = str(rng.choice(["none", "none", "raw", "threshold", "supra-threshold"]))
@@ -23,13 +23,26 @@ for k in range(n):
     ref = np.stack([np.stack([0.45 + 0.3 * np.sin(2 * np.pi * (3.1 * x / W + f / 9.0) + c) * np.cos(2 * np.pi * 2.3 * y / H) for c in range(3)])
                     for f in range(F)], axis=1)[None]
     test = np.clip(ref + 0.05 * rng.standard_normal(ref.shape), 0, 1)
-    test, ref = np.round(test * 255).astype(np.uint8), np.round(np.clip(ref, 0, 1) * 255).astype(np.uint8)
+    dt = str(rng.choice(["u8", "u8", "u16", "f32", "f16"]))
+    B = 1 if heat else int(rng.choice([1, 1, 2]))
+    if B == 2:                                        # a batch with a broadcast reference (video_source.py:247-252)
+        test = np.concatenate([test, np.clip(test + 0.02 * rng.standard_normal(test.shape), 0, 1)], axis=0)
+    if rng.random() < 0.15:                           # luminance-only content
+        test, ref = test[:, :1], ref[:, :1]
+    if dt == "u8":
+        test, ref = np.round(test * 255).astype(np.uint8), np.round(np.clip(ref, 0, 1) * 255).astype(np.uint8)
+    elif dt == "u16":
+        test, ref = np.round(test * 65535).astype(np.uint16), np.round(np.clip(ref, 0, 1) * 65535).astype(np.uint16)
+    elif dt == "f16":
+        test, ref = torch.tensor(test.astype(np.float16)), torch.tensor(np.clip(ref, 0, 1).astype(np.float16))
+    else:
+        test, ref = test.astype(np.float32), np.clip(ref, 0, 1).astype(np.float32)
     o = orc.Oracle(display_name=disp, temp_padding=pad, heatmap=heat)
     oj, os_ = o.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
     m = cv.cvvdp(display_name=disp, temp_padding=pad, heatmap=heat, block_frames=int(rng.choice([1, 2, 64])))
     j, s = m.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
     dq = np.abs(s["Q_per_ch"] - os_["Q_per_ch"]) / (np.abs(os_["Q_per_ch"]) * 2e-4 + 2e-6)
-    msg = f"{k:3d} {W}x{H}x{F} fps {fps} {disp} {pad} heat {heat}: dJOD {abs(float(j) - float(oj)):.2e}  Q err/tol {dq.max():.2f}"
+    msg = f"{k:3d} {W}x{H}x{F} B{B} {dt} C{test.shape[1]} fps {fps} {disp} {pad} heat {heat}: dJOD {abs(float(j) - float(oj)):.2e}  Q err/tol {dq.max():.2f}"
     ok = abs(float(j) - float(oj)) <= 1e-3 and dq.max() <= 1.0
     if heat:
         a = s["heatmap"].numpy().astype(np.float32)

@@ -1,4 +1,4 @@
-// K3..K7 fused, vectorised variant for wide levels (W % 8 == 0): same arithmetic as band.hip, laid out
+// K3..K7 fused, vectorised variant for every level of at least 16 x 16 pixels: same arithmetic as band.hip, laid out
 // for CDNA4 memory instructions.
 //
 //   wave  <-> colour/temporal channel c (so q_c, the cross-channel weights into c and the CSF row of c
@@ -6,27 +6,28 @@
 //   lane  <-> 4 adjacent columns        (16-byte global loads of g, ds_read_b128/ds_write_b128 for every
 //             per-row exchange, 4 independent SFU chains per lane)
 //   block <-> strip of 240 interior columns (+8 aligned halo columns each side), marching down a row
-//             segment exactly like k_band.
+//             segment exactly like k_band; blocks are ordered so that one XCD works on neighbouring strips.
 //
 // Two barriers per row; every row index is wave-uniform (SALU address arithmetic), the loop is unrolled over
 // an even/odd row pair so that the expand's row parity and the two g-row register sets are static:
 //
 //   phase 1:  pooling stage of the row finished last iteration (reads s_q of all channels, s_d)
-//             contrast/CSF stage of row r (reads s_ve, s_lum; writes s_m and the s_d ring)
+//             contrast stage of row r (reads s_ve, s_lum, s_S; writes s_m and the s_d ring)
 //             vertical expand of row r+1 from the rolling 3-row coarse window -> s_ve
 //   barrier
-//   phase 2:  loads: ONE coarse row (the window's next row) and the g rows of row r+2 (into the registers row r
-//             just left: two static register sets, no copies); luminance terms of row r+1 -> s_lum;
-//             13-tap horizontal blur (5 ds_read_b128), 13-row register window, vertical blur,
-//             Mq = (blur*10^mask_c + eps)^q_c -> s_q
+//   phase 2:  loads: the g rows of row r+2 (into the registers row r just left: two static register sets, no
+//             copies) and, on odd rows, ONE coarse row (the window's next row); luminance terms and CSF
+//             sensitivities of row r+1 -> s_lum, s_S; 13-tap horizontal blur (5 ds_read_b128), 13-row register
+//             window, vertical blur, Mq = (blur*10^mask_c + eps)^q_c -> s_q
 //   barrier
 //
-// Every lane issues every load on every row (clamped addresses), so the number of loads in flight is the same on
-// every path and the compiler waits with exact vmcnt(N) counts: coarse row first, then the two g rows, which
-// therefore stay in flight for two whole rows.
+// The streamed loads are issued from inline assembly and waited for with explicit vmcnt counts a whole row later
+// (see STREAM LOADS below); tools/check_band4_isa.py checks the generated code.  Rows reflected at the image's top /
+// bottom edge run in separate copies of the loop that reload the coarse window.
 //
 // Image-edge halo columns are produced by the in-image lanes as mirrored LDS writes (reflect padding
-// of the blur), halo rows by evaluating the reflected row (the coarse window follows the row index up or down).
+// of the blur), halo rows by evaluating the reflected row.  Instantiations: NCH (3 image / 4 video channels), HEAT
+// (per-pixel heat-map band), RAGGED (W % 8 != 0: partial last lane, shifted coarse chunks), DUMP (per-pixel D).
 #include <type_traits>
 #include "kernels.h"
 

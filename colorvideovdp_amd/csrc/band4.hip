@@ -139,8 +139,10 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   float inv_dmax = a.inv_dmax;
   if constexpr (!RAGGED) {   // (the ragged instantiation is short of VGPRs instead)
     B4_IN_VGPR(ind_k0); B4_IN_VGPR(xw1); B4_IN_VGPR(xw2); B4_IN_VGPR(xw3); B4_IN_VGPR(m1c); B4_IN_VGPR(inv_dmax);
-    B4_IN_VGPR(e0); B4_IN_VGPR(e1); B4_IN_VGPR(eo); B4_IN_VGPR(mask_p); B4_IN_VGPR(eps_p);
-    B4_IN_VGPR(qc); B4_IN_VGPR(ind_k1); B4_IN_VGPR(xw0);
+    if constexpr (!HEAT && !DUMP) {   // (those instantiations have no VGPRs to spare)
+      B4_IN_VGPR(e0); B4_IN_VGPR(e1); B4_IN_VGPR(eo); B4_IN_VGPR(mask_p); B4_IN_VGPR(eps_p);
+      B4_IN_VGPR(qc); B4_IN_VGPR(ind_k1); B4_IN_VGPR(xw0);
+    }
   }
 #undef B4_IN_VGPR
 
@@ -282,12 +284,15 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     const f4 d = lds_read4(&s_d[k7][c][4 * j - B4_HALO]);
     float D[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int h = 0; h < 2; ++h) {      // two column pairs: the mask sum and the clamp denominator as packed FMAs (-1.5 %; packing the
+                                       // expand or the vertical combine as well costs registers: slower, profiles/r02_dev_notes.txt)
+      const v2f Q0 = {q0.v[2 * h], q0.v[2 * h + 1]}, Q1 = {q1.v[2 * h], q1.v[2 * h + 1]}, Q2 = {q2.v[2 * h], q2.v[2 * h + 1]}, Q3 = {q3.v[2 * h], q3.v[2 * h + 1]};
       // 1 + M, M = sum_k xw[k][c] * ((blur_k*10^mask_c + eps)^q_k - eps^q_k)     (cvvdp_metric.py:758-760, :849)
-      const float M1 = q3.v[i] * xw3 + (q2.v[i] * xw2 + (q1.v[i] * xw1 + (q0.v[i] * xw0 + m1c)));
-      // Du = X/(1+M); D = dmax*Du/(dmax+Du) = X / ((1+M) + X/dmax): one reciprocal (:855-856, :949-950)
-      const float X = fast_pow(d.v[i], mask_p) - eps_p;          // s_d holds |T'-R'| + eps
-      D[i] = X * fast_rcp(X * inv_dmax + M1);
+      const v2f M1 = Q3 * xw3 + (Q2 * xw2 + (Q1 * xw1 + (Q0 * xw0 + m1c)));
+      // Du = X/(1+M); D = dmax*Du/(dmax+Du) = X / ((1+M) + X/dmax): one reciprocal (:855-856, :949-950); s_d holds |T'-R'| + eps
+      const v2f X = {fast_pow(d.v[2 * h], mask_p) - eps_p, fast_pow(d.v[2 * h + 1], mask_p) - eps_p};
+      const v2f T = X * inv_dmax + M1;
+      D[2 * h] = X.x * fast_rcp(T.x); D[2 * h + 1] = X.y * fast_rcp(T.y);
     }
     if (ragged_blk) {                                              // columns right of the image do not exist
 #pragma unroll

@@ -36,7 +36,8 @@ def check_kernel(name, lines):
     n_loads = 0
     for lo, hi in loops:
         body = lines[lo:hi + 1]
-        if not any("global_load_dwordx4" in l and " nt" in l for l in body):
+        # streaming loops = loops that contain a hand-issued load (inline asm shows up between ;;#ASMSTART / ;;#ASMEND)
+        if not any("global_load_dwordx4" in l and "ASMSTART" in body[i - 1] for i, l in enumerate(body) if i > 0):
             continue
         queue = []                 # in-flight loads, oldest first: (set of regs, text)
         for it in range(2):

@@ -6,8 +6,9 @@ file name carries size, frame rate, bit depth and chroma format, video_source_yu
 same output lines (`cvvdp=9.1234 [JOD]`, or only the number with --quiet), same side outputs (--result CSV, --features
 JSON, --distogram PNG, --heatmap).  Differences, because this image has no ffmpeg and the build is GPU-only:
   * compressed video files (.mp4, .mkv, ...) are refused with a hint to decode them to .yuv first;
-  * the heat map of a VIDEO is written as a numbered PNG sequence `<base>_heatmap_%05d.png` streamed block by block
-    (`ffmpeg -i <base>_heatmap_%05d.png <base>_heatmap.mp4` gives the reference's file); an image gives `<base>_heatmap.png`;
+  * the heat map of a VIDEO is streamed block by block: into `<base>_heatmap.mp4` through an ffmpeg pipe (the reference's
+    file and codec settings) where an `ffmpeg` executable exists, otherwise into a numbered PNG sequence
+    `<base>_heatmap_%05d.png` (`ffmpeg -i <base>_heatmap_%05d.png <base>_heatmap.mp4` converts it); an image gives `<base>_heatmap.png`;
   * --device must be a cuda device; --temp-padding 'valid', --full-screen-resize, --temp-resample, --dump-channels and
     metrics other than cvvdp are not available.
 """
@@ -274,10 +275,19 @@ def run_on_args(args):
                 is_video = vs.get_video_size()[2] > 1
                 sink = None
                 if args.heatmap and is_video:          # streamed to disk block by block: bounded host memory at any clip length
-                    pattern = os.path.join(out_dir, base + "_heatmap_%05d.png")
-                    logging.info(f"Writing heat map frames '{pattern}' ...")
-                    sink = heatmap_writers.HeatmapPngWriter(pattern)
-                Q_pred, stats = mm.predict_video_source(vs, heatmap_sink=sink) if sink is not None else mm.predict_video_source(vs)
+                    if heatmap_writers.HeatmapVideoWriter.available():     # the reference's file (run_cvvdp.py:349-354)
+                        dest = os.path.join(out_dir, base + "_heatmap.mp4")
+                        logging.info(f"Writing heat map '{dest}' ...")
+                        sink = heatmap_writers.HeatmapVideoWriter(dest, vs.get_frames_per_second(), verbose=args.verbose)
+                    else:
+                        pattern = os.path.join(out_dir, base + "_heatmap_%05d.png")
+                        logging.info(f"Writing heat map frames '{pattern}' ...")
+                        sink = heatmap_writers.HeatmapPngWriter(pattern)
+                try:
+                    Q_pred, stats = mm.predict_video_source(vs, heatmap_sink=sink) if sink is not None else mm.predict_video_source(vs)
+                finally:
+                    if sink is not None:
+                        sink.close()
                 q = Q_pred.item()
                 print(f"{q:0.4f}" if args.quiet else f"{mm.short_name()}={q:0.4f} [{mm.quality_unit()}]")
                 if res_fh is not None:

@@ -4,12 +4,15 @@ The reference returns the whole heat map as one fp16 CPU tensor (cvvdp_metric.py
 it into an .mp4 through an ffmpeg pipe or into a .png (run_cvvdp.py:44-78,349-363).  At 8K x 256 frames that tensor is
 51 GB, so here the metric can hand the frames over block by block instead; these sinks put them on disk with bounded
 memory.  ffmpeg is not a dependency: videos become a numbered PNG sequence (`ffmpeg -i base_%05d.png out.mp4` turns it
-into the reference's format) or one .npy file with the reference's array layout.
+into the reference's format) or one .npy file with the reference's array layout; where an `ffmpeg` executable is on the
+PATH, HeatmapVideoWriter pipes the frames into it and produces the reference's .mp4 directly.
 
 A sink is any callable `sink(first_frame, frames)`; `frames` is a float16 CPU tensor [1, 1|3, n, H, W] with values in
 [0, 1] (colour-mapped modes) that is only valid during the call.
 """
 import os
+import shutil
+import subprocess
 
 import numpy as np
 
@@ -43,6 +46,45 @@ class HeatmapPngWriter:
 
     def close(self):
         pass
+
+
+class HeatmapVideoWriter:
+    """The reference's heat-map video (run_cvvdp.py:44-66 np2vid): raw rgb24 frames piped into `ffmpeg`, mpeg4 codec at
+    qscale 3, the clip's frame rate.  The process is started with the first block (the frame size is known then) and
+    closed by close(); `available()` tells whether an ffmpeg executable exists on this machine."""
+
+    def __init__(self, path, fps, verbose=False, ffmpeg=None):
+        self.path, self.fps, self.verbose = path, fps, verbose
+        self.exe = ffmpeg or shutil.which("ffmpeg")
+        if self.exe is None:
+            raise FileNotFoundError("no ffmpeg executable on the PATH (use HeatmapPngWriter / HeatmapNpyWriter instead)")
+        d = os.path.dirname(path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        self.proc = None
+        self.frames_written = 0
+
+    @staticmethod
+    def available():
+        return shutil.which("ffmpeg") is not None
+
+    def __call__(self, first_frame, frames):
+        rgb = heatmap_to_uint8(frames)
+        if self.proc is None:
+            h, w = rgb.shape[1:3]
+            cmd = [self.exe, "-hide_banner", "-loglevel", "info" if self.verbose else "quiet", "-f", "rawvideo", "-pix_fmt", "rgb24",
+                   "-s", f"{w}x{h}", "-r", f"{self.fps:g}", "-i", "pipe:", "-f", "mp4", "-c:v", "mpeg4", "-qscale:v", "3", "-y", self.path]
+            self.proc = subprocess.Popen(cmd, stdin=subprocess.PIPE)
+        self.proc.stdin.write(rgb.tobytes())
+        self.frames_written += rgb.shape[0]
+
+    def close(self):
+        if self.proc is not None:
+            self.proc.stdin.close()
+            rc = self.proc.wait()
+            self.proc = None
+            if rc != 0:
+                raise RuntimeError(f"ffmpeg exited with status {rc} while writing '{self.path}'")
 
 
 class HeatmapNpyWriter:

@@ -96,3 +96,39 @@ def test_image_pairs_quiet_and_interactive(tmp_path, capsys, monkeypatch):
     out = capsys.readouterr().out.strip().splitlines()
     assert len(out) == 2 and all(abs(float(o) - float(g["jod"])) <= JOD_TOL for o in out)
     assert rc.main(["-t", str(tmp_path / "t.png"), "-r", str(tmp_path / "clip.mp4")]) == 1   # mixed / unsupported kinds are refused
+
+
+def test_heatmap_video_writer_pipes_rgb24_frames_into_ffmpeg(tmp_path):
+    """HeatmapVideoWriter speaks the reference's ffmpeg protocol (run_cvvdp.py:44-66): rawvideo rgb24 on stdin, size and
+    frame rate on the command line, mpeg4 / qscale 3 output.  Checked with a stand-in executable that records both."""
+    import stat
+    import torch
+    from colorvideovdp_amd import heatmap_writers as hw
+    fake = tmp_path / "ffmpeg"
+    fake.write_text("#!/usr/bin/env python3\nimport sys\nout = sys.argv[-1]\nopen(out + '.args', 'w').write('\\n'.join(sys.argv[1:]))\n"
+                    "open(out, 'wb').write(sys.stdin.buffer.read())\n")
+    fake.chmod(fake.stat().st_mode | stat.S_IXUSR)
+    dest = tmp_path / "out" / "clip_heatmap.mp4"
+    w = hw.HeatmapVideoWriter(str(dest), 30, ffmpeg=str(fake))
+    rng = np.random.default_rng(3)
+    frames = torch.tensor(rng.random((1, 3, 5, 6, 8)).astype(np.float16))
+    w(0, frames[:, :, :2])
+    w(2, frames[:, :, 2:])
+    w.close()
+    assert w.frames_written == 5
+    args = open(str(dest) + ".args").read().split("\n")
+    for flag, val in (("-f", "rawvideo"), ("-pix_fmt", "rgb24"), ("-s", "8x6"), ("-r", "30"), ("-c:v", "mpeg4"), ("-qscale:v", "3")):
+        assert args[args.index(flag) + 1] == val, (flag, args)
+    got = np.frombuffer(open(dest, "rb").read(), np.uint8).reshape(5, 6, 8, 3)
+    np.testing.assert_array_equal(got, hw.heatmap_to_uint8(frames))
+    # a failing encoder is an error, not a silent truncation
+    bad = tmp_path / "ffmpeg_bad"
+    bad.write_text("#!/usr/bin/env python3\nimport sys\nsys.stdin.buffer.read()\nsys.exit(3)\n")
+    bad.chmod(bad.stat().st_mode | stat.S_IXUSR)
+    w = hw.HeatmapVideoWriter(str(tmp_path / "x.mp4"), 24, ffmpeg=str(bad))
+    w(0, frames)
+    with pytest.raises(RuntimeError):
+        w.close()
+    if not hw.HeatmapVideoWriter.available():
+        with pytest.raises(FileNotFoundError):
+            hw.HeatmapVideoWriter(str(tmp_path / "y.mp4"), 24)

@@ -11,6 +11,7 @@ JSON, --distogram PNG, --heatmap).  Differences, because this image has no ffmpe
     `<base>_heatmap_%05d.png` (`ffmpeg -i <base>_heatmap_%05d.png <base>_heatmap.mp4` converts it); an image gives `<base>_heatmap.png`;
   * --device must be a cuda device; --temp-padding 'valid', --full-screen-resize, --temp-resample, --dump-channels and
     metrics other than cvvdp are not available.
+Clips stored as numbered image frames work as in the reference: `-t t_%04d.png -r r_%04d.png --fps 30 [--frames 10:2:50]`.
 """
 import argparse
 import glob
@@ -26,12 +27,9 @@ import torch
 from . import heatmap_writers
 from .cvvdp_metric import cvvdp
 from .display_model import vvdp_display_geometry, vvdp_display_photometry
-from .video_source import video_source_array
-from .video_source_yuv import video_source_yuv_file
+from .video_source_file import IMAGE_EXT, VIDEO_EXT, load_image_as_array, video_source_file
 from .vq_metric import vq_exception, vq_metric_dict
 
-IMAGE_EXT = (".png", ".jpg", ".jpeg", ".bmp", ".tif", ".tiff", ".ppm", ".pgm")
-VIDEO_EXT = (".mp4", ".mkv", ".mov", ".avi", ".webm", ".m4v", ".y4m")
 
 
 def expand_wildcards(filestrs):
@@ -64,8 +62,8 @@ _OPTIONS = (
     (("-m", "--metric"), dict(nargs="+", default=["cvvdp"], help="metric(s); this build registers cvvdp")),
     (("--temp-padding",), dict(choices=["replicate", "symmetric", "valid"], default="symmetric", help="padding before the first frame ('valid': " + _NA + ")")),
     (("--pix-per-deg",), dict(type=float, default=None, help="override the display geometry")),
-    (("--fps",), dict(type=float, default=None, help="frame rate: needed for .npy clips, overrides a .yuv file name")),
-    (("--frames",), dict(type=str, default=None, help=_NA)),
+    (("--fps",), dict(type=float, default=None, help="frame rate: needed for .npy clips and numbered image frames (name_%%04d.png), overrides a .yuv file name")),
+    (("--frames",), dict(type=str, default=None, help="frames of an image sequence to use: first:step:last, first:last or first: (both ends included)")),
     (("--gpu-mem",), dict(type=float, default=None, help="GPU memory budget in GB")),
     (("-q", "--quiet"), dict(action="store_true", default=False, help="print the JOD value only")),
     (("-v", "--verbose"), dict(action="store_true", default=False, help="more log output")),
@@ -86,114 +84,24 @@ def parse_args(arg_list=None):
     return p.parse_args(arg_list)
 
 
-def _png_is_16bit_colour(fname):
-    with open(fname, "rb") as f:
-        head = f.read(26)
-    return head[:8] == b"\x89PNG\r\n\x1a\n" and head[12:16] == b"IHDR" and head[24] == 16 and head[25] in (2, 6)
+def load_source(test_file, ref_file, display_photometry, config_paths, nframes=-1, fps=None, frame_range=None, full_screen_resize=None,
+                resize_resolution=None):
+    """The reference's video_source_file dispatch (run_cvvdp.py:296-318) for the formats available here; returns the source
+    that does the work."""
+    return video_source_file(test_file, ref_file, display_photometry=display_photometry, config_paths=config_paths, frames=nframes, fps=fps,
+                             frame_range=frame_range, full_screen_resize=full_screen_resize, resize_resolution=resize_resolution).vs
 
 
-def _read_png16(fname):
-    """16-bit RGB(A) PNG -> uint16 [H, W, 3].  Pillow reduces these to 8 bit, which moves the metric by several 1e-3 JOD
-    (the reference's own example image, example_media/wavy_facade.png, is such a file), so they are decoded here:
-    zlib stream + the five PNG row filters (PNG specification, section 9)."""
-    import struct
-    import zlib
-    data = open(fname, "rb").read()
-    pos, idat = 8, b""
-    while pos < len(data):
-        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
-        body = data[pos + 8:pos + 8 + n]
-        pos += 12 + n
-        if typ == b"IHDR":
-            w, h, depth, ctype, _, _, interlace = struct.unpack(">IIBBBBB", body)
-            if interlace:
-                raise vq_exception(f"'{fname}': interlaced 16-bit PNGs are not supported")
-        elif typ == b"IDAT":
-            idat += body
-        elif typ == b"IEND":
-            break
-    ch = 3 if ctype == 2 else 4
-    bpp, stride = 2 * ch, w * 2 * ch
-    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, stride + 1)
-    out = np.zeros((h, stride), dtype=np.uint8)
-    prev = np.zeros(stride, dtype=np.int32)
-    for y in range(h):
-        ft, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
-        if ft == 0:
-            cur = line
-        elif ft == 2:                                   # Up
-            cur = (line + prev) & 255
-        elif ft == 1:                                   # Sub: a running sum per byte lane
-            cur = (np.cumsum(line.reshape(w, bpp), axis=0) & 255).reshape(-1)
-        else:                                           # Average / Paeth depend on the pixel to the left: sequential
-            cur = line.copy()
-            for i in range(stride):
-                a = cur[i - bpp] if i >= bpp else 0
-                b = prev[i]
-                if ft == 3:
-                    pred = (a + b) >> 1
-                else:
-                    c = prev[i - bpp] if i >= bpp else 0
-                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
-                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
-                cur[i] = (cur[i] + pred) & 255
-        out[y] = cur
-        prev = cur
-    px = out.reshape(h, w, ch, 2).astype(np.uint16)
-    return np.ascontiguousarray(((px[..., 0] << 8) | px[..., 1])[..., :3])
-
-
-def _read_image(fname):
-    """8- or 16-bit image file -> uint8 / uint16 array [H, W, C] (the reference reads them with imageio, video_source_file.py)."""
-    if _png_is_16bit_colour(fname):
-        return _read_png16(fname)
-    from PIL import Image
-    with Image.open(fname) as im:
-        if im.mode in ("I;16", "I;16B", "I;16L", "I"):
-            a = np.asarray(im).astype(np.uint16)[..., None]
-        elif im.mode in ("L", "P", "1"):
-            a = np.asarray(im.convert("L"))[..., None]
-        else:
-            a = np.asarray(im.convert("RGB"))
-            if a.dtype not in (np.uint8, np.uint16):
-                a = a.astype(np.uint8)
-    return np.ascontiguousarray(a)
-
-
-def load_source(test_file, ref_file, display_photometry, config_paths, nframes=-1, fps=None):
-    """The reference's video_source_file dispatch (run_cvvdp.py:296-318) for the formats available here."""
-    ext = {os.path.splitext(f)[1].lower() for f in (test_file, ref_file)}
-    if len(ext) != 1:
-        raise vq_exception(f"Test and reference must be files of the same kind ('{test_file}' vs '{ref_file}')")
-    ext = ext.pop()
-    for f in (test_file, ref_file):
-        if not os.path.isfile(f):
-            raise vq_exception(f"File not found: '{f}'")
-    if ext == ".yuv":
-        vs = video_source_yuv_file(test_file, ref_file, display_photometry=display_photometry, frames=nframes, config_paths=config_paths)
-        if fps is not None:
-            vs.test_vidr.avg_fps = vs.reference_vidr.avg_fps = fps
-        return vs
-    if ext in IMAGE_EXT:
-        t, r = _read_image(test_file), _read_image(ref_file)
-        if t.shape != r.shape or t.dtype != r.dtype:
-            raise vq_exception(f"Test and reference images differ in size or bit depth: {t.shape} {t.dtype} vs {r.shape} {r.dtype}")
-        return video_source_array(t, r, 0, dim_order="HWC", display_photometry=display_photometry)
-    if ext == ".npy":
-        t, r = np.load(test_file, mmap_mode="r"), np.load(ref_file, mmap_mode="r")
-        if t.ndim == 3:
-            return video_source_array(np.ascontiguousarray(t), np.ascontiguousarray(r), 0, dim_order="HWC", display_photometry=display_photometry)
-        if t.ndim != 4:
-            raise vq_exception(".npy inputs must be [H, W, C] images or [F, H, W, C] videos")
-        if not fps:
-            raise vq_exception("--fps is required for .npy videos")
-        if nframes > 0:
-            t, r = t[:nframes], r[:nframes]
-        return video_source_array(np.ascontiguousarray(t), np.ascontiguousarray(r), fps, dim_order="FHWC", display_photometry=display_photometry)
-    if ext in VIDEO_EXT:
-        raise vq_exception(f"'{test_file}': compressed video files need ffmpeg, which this build does not use. Decode both clips to planar "
-                           f".yuv first, e.g. `ffmpeg -i clip.mp4 -pix_fmt yuv420p clip_1920x1080_30fps_420p8.yuv`")
-    raise vq_exception(f"Unsupported file type '{ext}'")
+def parse_frame_range(spec):
+    """--frames first:step:last | first:last | first:   (Matlab notation, both ends included; run_cvvdp.py:143-157)."""
+    if spec is None:
+        return None
+    ss = spec.split(":")
+    sn = [0, 1, 10000] if len(ss) == 3 else [0, 10000]
+    for kk in range(min(len(ss), len(sn))):
+        if ss[kk].isnumeric():
+            sn[kk] = int(ss[kk])
+    return range(sn[0], sn[2] + 1, sn[1]) if len(ss) == 3 else range(sn[0], sn[1] + 1)
 
 
 def run_on_args(args):
@@ -206,7 +114,8 @@ def run_on_args(args):
     if args.test is None or args.ref is None:
         logging.error("Paths to both test and reference content needs to be specified.")
         return
-    for opt, what in ((args.full_screen_resize, "--full-screen-resize"), (args.frames, "--frames"), (args.dump_channels, "--dump-channels")):
+    frame_range = parse_frame_range(args.frames)
+    for opt, what in ((args.full_screen_resize, "--full-screen-resize"), (args.dump_channels, "--dump-channels")):
         if opt is not None:
             raise vq_exception(f"{what} is not available in the MI355X build")
     if args.temp_resample >= 0:
@@ -269,7 +178,7 @@ def run_on_args(args):
                 res_fh.write(f"{test_file}, {ref_file}")
             logging.info(f"Predicting the quality of '{test_file}' compared to '{ref_file}'")
             for mm in metrics:
-                vs = load_source(test_file, ref_file, display_photometry, args.config_paths, nframes=args.nframes, fps=args.fps)
+                vs = load_source(test_file, ref_file, display_photometry, args.config_paths, nframes=args.nframes, fps=args.fps, frame_range=frame_range)
                 base = os.path.splitext(os.path.basename(test_file))[0]
                 mm.set_base_fname(os.path.join(out_dir, base))
                 is_video = vs.get_video_size()[2] > 1

@@ -38,9 +38,9 @@ def test_refusals_need_no_gpu(tmp_path, capsys):
     img = (np.arange(64 * 48 * 3).reshape(48, 64, 3) % 251).astype(np.uint8)
     from PIL import Image
     Image.fromarray(img).save(tmp_path / "a.png")
-    assert np.array_equal(rc._read_image(str(tmp_path / "a.png")), img)
+    assert np.array_equal(rc.load_image_as_array(str(tmp_path / "a.png")), img)
     Image.fromarray(img[..., 0]).save(tmp_path / "g.png")
-    assert rc._read_image(str(tmp_path / "g.png")).shape == (48, 64, 1)
+    assert rc.load_image_as_array(str(tmp_path / "g.png")).shape == (48, 64, 1)
 
 
 @pytest.mark.gpu
@@ -132,3 +132,79 @@ def test_heatmap_video_writer_pipes_rgb24_frames_into_ffmpeg(tmp_path):
     if not hw.HeatmapVideoWriter.available():
         with pytest.raises(FileNotFoundError):
             hw.HeatmapVideoWriter(str(tmp_path / "y.mp4"), 24)
+
+
+def _write_png16(path, a):
+    """uint16 [H, W, 3] -> 16-bit RGB PNG (filter type 0 on every row); Pillow cannot write these."""
+    import struct
+    import zlib
+    h, w, _ = a.shape
+    raw = b"".join(b"\0" + a[y].astype(">u2").tobytes() for y in range(h))
+
+    def chunk(typ, body):
+        return struct.pack(">I", len(body)) + typ + body + struct.pack(">I", zlib.crc32(typ + body) & 0xFFFFFFFF)
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def test_image_frame_sources_host_logic(tmp_path):
+    """video_source_image_frames (video_source_file.py:549-612): name patterns, frame counting, the reference's refusals."""
+    from PIL import Image
+    from colorvideovdp_amd import cli as rc, video_source_image_frames, vq_exception
+    conv = video_source_image_frames.convert_c2python_format_str
+    assert conv("a/f_%04d.png") == ("a/f_{:04d}.png", True) and conv("f%d.png") == ("f{:d}.png", True) and conv("plain.png") == ("plain.png", False)
+    img = (np.arange(24 * 32 * 3).reshape(24, 32, 3) % 251).astype(np.uint8)
+    for k in (0, 1, 2, 3, 5):                                        # frame 4 is missing
+        Image.fromarray(img + k).save(tmp_path / f"t_{k:03d}.png")
+        Image.fromarray(img).save(tmp_path / f"r_{k:03d}.png")
+    tp, rp = str(tmp_path / "t_%03d.png"), str(tmp_path / "r_%03d.png")
+    vs = video_source_image_frames(tp, rp, fps=30, display_photometry="standard_fhd")
+    assert vs.get_video_size() == (24, 32, 4) and vs.get_frames_per_second() == 30 and list(vs.frame_range) == [0, 1, 2, 3]
+    t, r, code = vs.get_raw_block(1, 3, "cpu")
+    assert code == 0 and t.shape == (1, 3, 2, 24, 32) and np.array_equal(t[0, :, 1].numpy().transpose(1, 2, 0), img + 2) and np.array_equal(r[0, :, 0].numpy().transpose(1, 2, 0), img)
+    vs = video_source_image_frames(tp, rp, fps=30, frame_range=rc.parse_frame_range("1:2:9"), display_photometry="standard_fhd")
+    assert list(vs.frame_range) == [1, 3, 5]                             # 1:2:9 steps over the missing frame 4; frame 7 ends the run
+    assert list(rc.parse_frame_range("2:5")) == [2, 3, 4, 5] and list(rc.parse_frame_range("3:")[:2]) == [3, 4] and rc.parse_frame_range(None) is None
+    for args, kw in (((tp, str(tmp_path / "r_000.png")), dict(fps=30)), ((tp, rp), dict(fps=0)), ((str(tmp_path / "t_000.png"), str(tmp_path / "r_000.png")), dict(fps=30)),
+                     ((str(tmp_path / "x_%03d.png"), rp), dict(fps=30)), ((tp, rp), dict(fps=30, full_screen_resize="bilinear"))):
+        with pytest.raises(vq_exception):
+            video_source_image_frames(*args, display_photometry="standard_fhd", **kw)
+    a16 = (np.arange(10 * 12 * 3).reshape(10, 12, 3) * 181 % 65536).astype(np.uint16)
+    _write_png16(tmp_path / "p16.png", a16)
+    assert np.array_equal(rc.load_image_as_array(str(tmp_path / "p16.png")), a16)
+    vs = video_source_image_frames(str(tmp_path / "p16.png"), str(tmp_path / "p16.png"), display_photometry="standard_fhd")
+    t, r, code = vs.get_raw_block(0, 1, "cpu")
+    assert vs.get_video_size() == (10, 12, 1) and code == 1 and t.dtype.is_floating_point is False and np.array_equal(t[0, :, 0].numpy().view(np.uint16).transpose(1, 2, 0), a16)
+    with pytest.raises(FileNotFoundError):
+        video_source_image_frames(str(tmp_path / "nope.png"), str(tmp_path / "p16.png"), display_photometry="standard_fhd").get_video_size()
+
+
+@pytest.mark.gpu
+def test_numbered_image_frames_are_a_clip(tmp_path, capsys):
+    """A clip stored as numbered frames (-t t_%03d.png --fps 30) scores like the same clip handed over as an array: against the
+    reference's JOD for 8- and 16-bit frames (symmetric padding), and bit-exactly against predict() for a --frames subset."""
+    from PIL import Image
+    import colorvideovdp_amd as cv
+    from colorvideovdp_amd import cli as rc
+    g = load_golden("vid_u16_67x121x20_30_4k_sym")
+    for k in range(g["test"].shape[0]):
+        _write_png16(tmp_path / f"t16_{k:04d}.png", g["test"][k])
+        _write_png16(tmp_path / f"r16_{k:04d}.png", g["ref"][k])
+    assert rc.main(["-t", str(tmp_path / "t16_%04d.png"), "-r", str(tmp_path / "r16_%04d.png"), "--fps", "30", "-d", "standard_4k", "-q"]) == 0   # symmetric = CLI default
+    assert abs(float(capsys.readouterr().out.strip()) - float(g["jod"])) <= JOD_TOL
+    g = load_golden("vid_u8_72x128x12_60_fhd")
+    for k in range(g["test"].shape[0]):
+        Image.fromarray(g["test"][k]).save(tmp_path / f"t_{k:03d}.png")
+        Image.fromarray(g["ref"][k]).save(tmp_path / f"r_{k:03d}.png")
+    common = ["-t", str(tmp_path / "t_%03d.png"), "-r", str(tmp_path / "r_%03d.png"), "--fps", "60", "-d", "standard_fhd", "--temp-padding", "replicate", "-q"]
+    assert rc.main(common) == 0
+    assert abs(float(capsys.readouterr().out.strip()) - float(g["jod"])) <= JOD_TOL
+    assert rc.main(common + ["--frames", "1:2:9"]) == 0
+    got = float(capsys.readouterr().out.strip())
+    m = cv.cvvdp(display_name="standard_fhd", temp_padding="replicate")
+    want, _ = m.predict(g["test"][1:10:2], g["ref"][1:10:2], dim_order="FHWC", frames_per_second=60)
+    assert f"{got:.4f}" == f"{want.item():.4f}"
+    # the class directly, small blocks (frames are decoded block by block, the core keeps the temporal history)
+    vs = cv.video_source_file(str(tmp_path / "t_%03d.png"), str(tmp_path / "r_%03d.png"), fps=60, display_photometry="standard_fhd")
+    q1, s1 = cv.cvvdp(display_name="standard_fhd", temp_padding="replicate", block_frames=5).predict_video_source(vs)
+    q2, s2 = m.predict(g["test"], g["ref"], dim_order="FHWC", frames_per_second=60)
+    assert np.array_equal(s1["Q_per_ch"], s2["Q_per_ch"]) and q1.item() == q2.item()

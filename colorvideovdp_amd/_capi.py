@@ -12,7 +12,8 @@ MAX_WINDOW = 256
 CSF_NODES = 32
 PROF_N = 6
 PROF_NAMES = ("photometry", "temporal_fir", "pyr_reduce", "band_level0", "band_rest", "heatmap")
-ABI_VERSION = 7
+ABI_VERSION = 8
+RESIZE_MODES = {"nearest": 0, "bilinear": 1, "bicubic": 2, "area": 3}   # CVVDP_RESIZE_*
 
 U8, U16, F16, F32, F32_DKL, YUV8, YUV16 = range(7)
 HEATMAP = {None: 0, "none": 0, "raw": 1, "threshold": 2, "supra-threshold": 3}
@@ -82,6 +83,8 @@ SYMBOLS = {
                                       C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p]),
     "cvvdp_process_block_yuv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(YuvFormat), C.c_int32, C.POINTER(C.c_int32),
                                           C.c_int32, C.c_int32, C.c_void_p]),
+    "cvvdp_unpack_yuv_resized": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(YuvFormat), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvvdp_process_block_filtered": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                                C.c_int32, C.c_int32, C.c_void_p]),
     "cvvdp_get_features": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

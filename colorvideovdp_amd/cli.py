@@ -9,8 +9,8 @@ JSON, --distogram PNG, --heatmap).  Differences, because this image has no ffmpe
   * the heat map of a VIDEO is streamed block by block: into `<base>_heatmap.mp4` through an ffmpeg pipe (the reference's
     file and codec settings) where an `ffmpeg` executable exists, otherwise into a numbered PNG sequence
     `<base>_heatmap_%05d.png` (`ffmpeg -i <base>_heatmap_%05d.png <base>_heatmap.mp4` converts it); an image gives `<base>_heatmap.png`;
-  * --device must be a cuda device; --temp-padding 'valid', --full-screen-resize, --temp-resample, --dump-channels and
-    metrics other than cvvdp are not available.
+  * --device must be a cuda device; --temp-padding 'valid', --temp-resample, --dump-channels and metrics other than cvvdp are
+    not available; --full-screen-resize works for .yuv clips (as in the reference it is not implemented for images).
 Clips stored as numbered image frames work as in the reference: `-t t_%04d.png -r r_%04d.png --fps 30 [--frames 10:2:50]`.
 """
 import argparse
@@ -58,7 +58,8 @@ _OPTIONS = (
     (("-d", "--display"), dict(type=str, default="standard_4k", help="display model name; ? lists them")),
     (("-n", "--nframes"), dict(type=int, default=-1, help="use only the first N frames")),
     (("--count-frames",), dict(action="store_true", default=False, help="accepted for compatibility (frame counts of .yuv / .npy inputs are exact)")),
-    (("-f", "--full-screen-resize"), dict(choices=["bilinear", "bicubic", "nearest", "area"], default=None, help=_NA)),
+    (("-f", "--full-screen-resize"), dict(choices=["bilinear", "bicubic", "nearest", "area"], default=None,
+                                          help="resize test and reference to the display's resolution (.yuv clips; on the GPU, torch.nn.functional.interpolate semantics)")),
     (("-m", "--metric"), dict(nargs="+", default=["cvvdp"], help="metric(s); this build registers cvvdp")),
     (("--temp-padding",), dict(choices=["replicate", "symmetric", "valid"], default="symmetric", help="padding before the first frame ('valid': " + _NA + ")")),
     (("--pix-per-deg",), dict(type=float, default=None, help="override the display geometry")),
@@ -115,7 +116,7 @@ def run_on_args(args):
         logging.error("Paths to both test and reference content needs to be specified.")
         return
     frame_range = parse_frame_range(args.frames)
-    for opt, what in ((args.full_screen_resize, "--full-screen-resize"), (args.dump_channels, "--dump-channels")):
+    for opt, what in ((args.dump_channels, "--dump-channels"),):
         if opt is not None:
             raise vq_exception(f"{what} is not available in the MI355X build")
     if args.temp_resample >= 0:
@@ -178,7 +179,8 @@ def run_on_args(args):
                 res_fh.write(f"{test_file}, {ref_file}")
             logging.info(f"Predicting the quality of '{test_file}' compared to '{ref_file}'")
             for mm in metrics:
-                vs = load_source(test_file, ref_file, display_photometry, args.config_paths, nframes=args.nframes, fps=args.fps, frame_range=frame_range)
+                vs = load_source(test_file, ref_file, display_photometry, args.config_paths, nframes=args.nframes, fps=args.fps, frame_range=frame_range,
+                                 full_screen_resize=args.full_screen_resize, resize_resolution=display_geometry.resolution)
                 base = os.path.splitext(os.path.basename(test_file))[0]
                 mm.set_base_fname(os.path.join(out_dir, base))
                 is_video = vs.get_video_size()[2] > 1

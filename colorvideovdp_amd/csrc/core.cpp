@@ -429,16 +429,12 @@ int cvvdp_process_block(cvvdp_handle* h, const void* t, const void* r, int32_t d
   return process_block_impl(h, t, r, dtype, st, sr, nullptr, raw_first, hist_src, n_frames, q_frame_offset, stream);
 }
 
-int cvvdp_process_block_yuv(cvvdp_handle* h, const void* t, const void* r, const cvvdp_yuv_format* fmt, int32_t raw_first,
-                            const int32_t* hist_src, int32_t n_frames, int32_t q_frame_offset, void* stream) {
-  if (!h) return CVVDP_E_STATE;
+// format description -> the constants of the Y'CbCr unpack for W x H frames (shared by the fused temporal path and the resize path)
+static int fill_yuv(cvvdp_handle* h, const cvvdp_yuv_format* fmt, int W, int H, cvvdp::YuvArgs& y) {
   if (!fmt) return fail(h, CVVDP_E_ARG, "format missing");
-  const cvvdp_clip& c = h->c;
-  if (c.channels != 3 || c.batch != 1) return fail(h, CVVDP_E_ARG, "Y'CbCr input needs a clip configured with 3 channels and batch 1");
   if (fmt->bit_depth < 8 || fmt->bit_depth > 16) return fail(h, CVVDP_E_UNSUPPORTED, "bit depth %d unsupported", fmt->bit_depth);
   if (fmt->matrix != 709 && fmt->matrix != 2020) return fail(h, CVVDP_E_UNSUPPORTED, "matrix %d unsupported (709 or 2020)", fmt->matrix);
-  const int W = c.width, H = c.height;
-  cvvdp::YuvArgs y{};
+  y = cvvdp::YuvArgs{};
   if (fmt->chroma == 444) { y.Wc = W; y.Hc = H; y.inv_fx = 1.0f; y.inv_fy = 1.0f; }
   else if (fmt->chroma == 422) { y.Wc = W / 2; y.Hc = H; y.inv_fx = 0.5f; y.inv_fy = 1.0f; }
   else if (fmt->chroma == 420) { y.Wc = W / 2; y.Hc = H / 2; y.inv_fx = 0.5f; y.inv_fy = 0.5f; }
@@ -454,9 +450,39 @@ int cvvdp_process_block_yuv(cvvdp_handle* h, const void* t, const void* r, const
   y.wc = (float)(1.0 / (sc * 224.0)); y.oc = (float)(128.0 / 224.0);
   if (fmt->matrix == 2020) { y.rv = 1.47460f; y.gu = -0.16455f; y.gv = -0.57135f; y.bu = 1.88140f; }   // :151-154
   else { y.rv = 1.402f; y.gu = -0.344136f; y.gv = -0.714136f; y.bu = 1.772f; }                          // :157-160
+  return CVVDP_OK;
+}
+
+int cvvdp_process_block_yuv(cvvdp_handle* h, const void* t, const void* r, const cvvdp_yuv_format* fmt, int32_t raw_first,
+                            const int32_t* hist_src, int32_t n_frames, int32_t q_frame_offset, void* stream) {
+  if (!h) return CVVDP_E_STATE;
+  const cvvdp_clip& c = h->c;
+  if (c.channels != 3 || c.batch != 1) return fail(h, CVVDP_E_ARG, "Y'CbCr input needs a clip configured with 3 channels and batch 1");
+  const int W = c.width;
+  cvvdp::YuvArgs y;
+  if (int rc = fill_yuv(h, fmt, W, c.height, y)) return rc;
   const int64_t st[5] = {0, 0, fmt->frame_stride_test, W, 1}, sr[5] = {0, 0, fmt->frame_stride_ref, W, 1};
   return process_block_impl(h, t, r, fmt->bit_depth == 8 ? CVVDP_YUV8 : CVVDP_YUV16, st, sr, &y, raw_first, hist_src, n_frames,
                             q_frame_offset, stream);
+}
+
+int cvvdp_unpack_yuv_resized(cvvdp_handle* h, const void* codes, const cvvdp_yuv_format* fmt, int32_t is_ref, int32_t src_w, int32_t src_h,
+                             int32_t n_frames, int32_t dst_w, int32_t dst_h, int32_t mode, float* tmp, float* rgb, void* stream) {
+  if (!h) return CVVDP_E_STATE;
+  if (!codes || !tmp || !rgb || n_frames < 1 || src_w < 1 || src_h < 1 || dst_w < 1 || dst_h < 1) return fail(h, CVVDP_E_ARG, "bad resize arguments");
+  if (mode < CVVDP_RESIZE_NEAREST || mode > CVVDP_RESIZE_AREA) return fail(h, CVVDP_E_ARG, "resize mode %d unknown", mode);
+  cvvdp::YuvUnpackArgs u{};
+  if (int rc = fill_yuv(h, fmt, src_w, src_h, u.yuv)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  u.src = codes; u.W = src_w; u.H = src_h; u.n_frames = n_frames; u.bits16 = fmt->bit_depth > 8;
+  u.frame_stride = is_ref ? fmt->frame_stride_ref : fmt->frame_stride_test;
+  u.out = tmp;
+  cvvdp::launch_yuv_unpack(u, s);
+  cvvdp::ResizeArgs z{};
+  z.in = tmp; z.out = rgb; z.n_planes = 3 * n_frames; z.Hs = src_h; z.Ws = src_w; z.Hd = dst_h; z.Wd = dst_w; z.mode = mode;
+  z.sy = (float)src_h / (float)dst_h; z.sx = (float)src_w / (float)dst_w;        // area_pixel_compute_scale, align_corners = false
+  cvvdp::launch_resize(z, s);
+  return check_launch(h, "yuv resize");
 }
 
 static int process_block_impl(cvvdp_handle* h, const void* t, const void* r, int32_t dtype, const int64_t st[5], const int64_t sr[5],

@@ -60,6 +60,21 @@ struct YuvArgs {            // planar Y'CbCr sources (video_source_yuv.py:79-124
   float wy, oy, wc, oc;     // limited-range fixed point -> float: Y' = wy*code - oy, C = wc*code - oc
   float rv, gu, gv, bu;     // R' = Y' + rv*Cr, G' = Y' + gu*Cb + gv*Cr, B' = Y' + bu*Cb
 };
+struct YuvUnpackArgs {      // resize.hip: Y'CbCr frames -> fp32 R'G'B' planes [3][n_frames][H][W]
+  const void* src;
+  YuvArgs yuv;
+  int32_t W, H, n_frames, bits16;
+  int64_t frame_stride;     // samples
+  float* out;
+};
+struct ResizeArgs {         // resize.hip: n_planes fp32 planes [Hs][Ws] -> [Hd][Wd], clipped to [0,1]
+  const float* in;
+  float* out;
+  int32_t n_planes, Hs, Ws, Hd, Wd, mode;
+  float sy, sx;             // (float)Hs / Hd, (float)Ws / Wd
+};
+void launch_yuv_unpack(const YuvUnpackArgs& a, hipStream_t s);
+void launch_resize(const ResizeArgs& a, hipStream_t s);
 struct FirArgs {
   const void* src[2];      // raw test / reference frames handed to this block
   int64_t sb[2], sc[2], sf[2], sh[2], sw[2];  // element strides (B, C, F, H, W)

@@ -38,8 +38,8 @@ template <int DT> struct PixCtx { __device__ PixCtx(const FirArgs&, int, int, in
 struct YuvCtx {
   int32_t pix, o[4];       // luma offset in the frame; chroma tap offsets inside a chroma plane (y0x0, y0x1, y1x0, y1x1)
   float lx, ly;
-  __device__ YuvCtx(const FirArgs& a, int pix_, int y, int x) : pix(pix_) {
-    const YuvArgs& q = a.yuv;
+  __device__ YuvCtx(const FirArgs& a, int pix_, int y, int x) : YuvCtx(a.yuv, pix_, y, x) {}
+  __device__ YuvCtx(const YuvArgs& q, int pix_, int y, int x) : pix(pix_) {
     const float sx = fmaxf(((float)x + 0.5f) * q.inv_fx - 0.5f, 0.0f), sy = fmaxf(((float)y + 0.5f) * q.inv_fy - 0.5f, 0.0f);
     const int x0 = min((int)sx, q.Wc - 1), y0 = min((int)sy, q.Hc - 1);
     const int x1 = min(x0 + 1, q.Wc - 1), y1 = min(y0 + 1, q.Hc - 1);
@@ -70,23 +70,29 @@ __device__ __forceinline__ void load_pixels(const FirArgs& a, const PixCtx<DT>& 
   }
 }
 
+// One Y'CbCr pixel -> display-encoded R'G'B' in [0,1]: limited-range fixed point -> float (video_source_yuv.py:197-210),
+// bilinear chroma (:212-216), matrix + clip (:151-170)
+__device__ __forceinline__ void yuv_pixel_rgb(const YuvArgs& q, const YuvCtx& cx, const RawYuv& in, float (&v)[3]) {
+  const float Y = clipf(q.wy * (float)in.y - q.oy, 0.0f, 1.0f);
+  float ch[2];
+#pragma unroll
+  for (int pl = 0; pl < 2; ++pl) {
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = clipf(q.wc * (float)(pl == 0 ? in.u[k] : in.w[k]) - q.oc, -0.5f, 0.5f);
+    const float top = t[0] * (1.0f - cx.lx) + t[1] * cx.lx, bot = t[2] * (1.0f - cx.lx) + t[3] * cx.lx;
+    ch[pl] = top * (1.0f - cx.ly) + bot * cx.ly;
+  }
+  v[0] = clipf(Y + ch[1] * q.rv, 0.0f, 1.0f);
+  v[1] = clipf(Y + ch[0] * q.gu + ch[1] * q.gv, 0.0f, 1.0f);
+  v[2] = clipf(Y + ch[0] * q.bu, 0.0f, 1.0f);
+}
+
 template <int DT, int V>
 __device__ __forceinline__ void convert_pixels(const FirArgs& a, const PixCtx<DT>& cx, const Raw<DT, V>& in, float (&dkl)[3][V]) {
   if constexpr (is_yuv(DT)) {
-    const YuvArgs& q = a.yuv;
-    // limited-range fixed point -> float (video_source_yuv.py:197-210), bilinear chroma (:212-216), matrix + clip (:151-170)
-    const float Y = clipf(q.wy * (float)in.y - q.oy, 0.0f, 1.0f);
-    float ch[2];
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-      float t[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) t[k] = clipf(q.wc * (float)(pl == 0 ? in.u[k] : in.w[k]) - q.oc, -0.5f, 0.5f);
-      const float top = t[0] * (1.0f - cx.lx) + t[1] * cx.lx, bot = t[2] * (1.0f - cx.lx) + t[3] * cx.lx;
-      ch[pl] = top * (1.0f - cx.ly) + bot * cx.ly;
-    }
-    float v[3] = {clipf(Y + ch[1] * q.rv, 0.0f, 1.0f), clipf(Y + ch[0] * q.gu + ch[1] * q.gv, 0.0f, 1.0f),
-                  clipf(Y + ch[0] * q.bu, 0.0f, 1.0f)};
+    float v[3];
+    yuv_pixel_rgb(a.yuv, cx, in, v);
     float o[3];
     pixel_to_dkl(a.dm, v, o);
     dkl[0][0] = o[0]; dkl[1][0] = o[1]; dkl[2][0] = o[2];

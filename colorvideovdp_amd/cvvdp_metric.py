@@ -329,6 +329,25 @@ class cvvdp(vq_metric):
         # generic video_source: frames arrive one by one, already in DKL (cvvdp_metric.py:503-504)
         return self._seq_frames(vs).block(a, b)
 
+    def _yuv_block_resized(self, vs, a, b, height, width):
+        """Frames [a,b) of a .yuv pair with full_screen_resize: [1,3,n,H,W] fp32 R'G'B' blocks at the display's resolution
+        (cvvdp_unpack_yuv_resized: unpack + torch.nn.functional.interpolate semantics + clip, video_source_yuv.py:333-336)."""
+        lib = _capi.lib()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        out = []
+        for side in range(2):
+            codes, fmt, sw, sh = vs.get_raw_yuv_side(side, a, b, self.device)
+            # a side that already has the target size is not interpolated by the reference: nearest at scale 1 is the identity
+            mode = _capi.RESIZE_MODES[vs.full_screen_resize] if (sw, sh) != (width, height) else _capi.RESIZE_MODES["nearest"]
+            tmp = torch.empty(3 * (b - a) * sh * sw, dtype=torch.float32, device=self.device)
+            rgb = torch.empty((1, 3, b - a, height, width), dtype=torch.float32, device=self.device)
+            rc = lib.cvvdp_unpack_yuv_resized(self._handle, codes.data_ptr(), ctypes.byref(fmt), side, sw, sh, b - a, width, height, mode,
+                                              tmp.data_ptr(), rgb.data_ptr(), stream)
+            _capi.check(self._handle, rc, "cvvdp_unpack_yuv_resized")
+            out.append(rgb)
+            del tmp, codes            # stream-ordered: the caching allocator may reuse them once the kernels are queued
+        return out[0], out[1], _capi.F32
+
     def _seq_frames(self, vs, colorspace="DKLd65"):
         sf = getattr(self, "_seq", None)
         if sf is None or sf.vs is not vs or sf.colorspace != colorspace:
@@ -382,6 +401,9 @@ class cvvdp(vq_metric):
         rho_band = freqs.copy()
         rho_band[L - 1] = 0.1  # cvvdp_metric.py:685-686
         is_yuv = hasattr(vs, "get_raw_yuv_block")      # planar Y'CbCr file source: unpacked by the temporal kernel
+        # full_screen_resize (video_source_yuv.py:333-336): frames are unpacked to R'G'B' and resized on the GPU first, then
+        # take the fp32 route; a source whose files already have the target size takes the fused route like the reference
+        yuv_resized = is_yuv and bool(getattr(vs, "needs_resize", lambda: False)())
         generic = not self._is_raw_source(vs)           # frames arrive one by one, already in DKL
         # sources with temporally pre-filtered channels bypass the sliding window + FIR (cvvdp_metric.py:470-488)
         prefiltered = bool(getattr(vs, "is_temporally_filtered", False)) and not is_image
@@ -579,6 +601,8 @@ class cvvdp(vq_metric):
 
             def fetch(blk):
                 _, _, lo, hi, _ = blk
+                if yuv_resized:
+                    return self._yuv_block_resized(vs, lo, hi, height, width)
                 if is_yuv:
                     return vs.get_raw_yuv_block(lo, hi, self.device)
                 return self._raw_block(vs, lo, hi)
@@ -615,7 +639,7 @@ class cvvdp(vq_metric):
                     else:
                         t, r, third = fetch(blk)
                     hist_c = (ctypes.c_int32 * max(len(hist), 1))(*hist)
-                    if is_yuv:
+                    if is_yuv and not yuv_resized:
                         rc = lib.cvvdp_process_block_yuv(self._handle, t.data_ptr(), r.data_ptr(), ctypes.byref(third), ff - lo, hist_c, n,
                                                          ff - first, stream)
                         _capi.check(self._handle, rc, "cvvdp_process_block_yuv")

@@ -129,13 +129,26 @@ class video_source_yuv_file(video_source):
 
     def __init__(self, test_fname, reference_fname, display_photometry="standard_4k", frames=-1, full_screen_resize=None,
                  resize_resolution=None, retain_aspect_ratio=False, verbose=False, config_paths=[]):
-        if full_screen_resize is not None:
-            raise NotImplementedError("full_screen_resize is not supported: resize the clips before measuring them")
+        if full_screen_resize is not None and full_screen_resize not in _capi.RESIZE_MODES:
+            raise RuntimeError(f"full_screen_resize must be one of {sorted(_capi.RESIZE_MODES)}")
         self.reference_vidr = YUVReader(reference_fname)
         self.test_vidr = YUVReader(test_fname)
         t, r = self.test_vidr, self.reference_vidr
-        if (t.width, t.height, t.chroma_ss, t.bit_depth, t.color_space) != (r.width, r.height, r.chroma_ss, r.bit_depth, r.color_space):
+        # without a resize both files feed one fused kernel launch and must match; with it every side is unpacked and resized
+        # on its own, so e.g. a 1080p encode can be measured against its 4K source like in the reference
+        if full_screen_resize is None and (t.width, t.height, t.chroma_ss, t.bit_depth, t.color_space) != (r.width, r.height, r.chroma_ss, r.bit_depth, r.color_space):
             raise RuntimeError("Test and reference .yuv files must have the same resolution, chroma subsampling, bit depth and colour space")
+        self.full_screen_resize = full_screen_resize
+        if full_screen_resize is not None:
+            if resize_resolution is None:
+                raise RuntimeError("full_screen_resize needs resize_resolution = (width, height)")
+            if retain_aspect_ratio:                                   # video_source_yuv.py:273-282
+                h, w = t.height, t.width
+                if h / resize_resolution[1] * resize_resolution[0] <= w:
+                    resize_resolution = (resize_resolution[0], int(resize_resolution[0] / w * h))
+                else:
+                    resize_resolution = (int(resize_resolution[1] / h * w), resize_resolution[1])
+        self.resize_resolution = None if resize_resolution is None else (int(resize_resolution[0]), int(resize_resolution[1]))
         self.total_frames = self.test_vidr.frames
         self.frames = self.total_frames if frames == -1 else min(self.total_frames, frames)
         self.offset = 0
@@ -151,7 +164,17 @@ class video_source_yuv_file(video_source):
                           f"EOTF: {self.dm_photometry.EOTF}, fps: {vr.avg_fps}, frames: {self.frames}")
 
     def get_video_size(self):
+        if self.full_screen_resize is not None:                       # video_source_yuv.py:308-312
+            return [self.resize_resolution[1], self.resize_resolution[0], self.frames]
         return [self.test_vidr.height, self.test_vidr.width, self.frames]
+
+    def needs_resize(self):
+        """Does any side have to be interpolated (or unpacked on its own because the two files differ)?"""
+        if self.full_screen_resize is None:
+            return False
+        t, r = self.test_vidr, self.reference_vidr
+        same = (t.width, t.height, t.chroma_ss, t.bit_depth, t.color_space) == (r.width, r.height, r.chroma_ss, r.bit_depth, r.color_space)
+        return not same or (t.width, t.height) != self.resize_resolution
 
     def get_frames_per_second(self):
         return self.test_vidr.avg_fps
@@ -177,20 +200,30 @@ class video_source_yuv_file(video_source):
 
     get_reference_frame = get_test_frame
 
-    # raw access used by the metric (cvvdp_process_block_yuv)
+    # raw access used by the metric (cvvdp_process_block_yuv / cvvdp_unpack_yuv_resized)
+    def _upload(self, vr, first, last, device):
+        a = vr.raw_frames(self.offset + first, self.offset + last)
+        tdt = torch.int16 if a.dtype == np.uint16 else torch.uint8   # torch has no uint16: keep the bit pattern
+        try:
+            host = torch.empty(a.shape, dtype=tdt, pin_memory=True)   # page-locked staging: the H2D copy is asynchronous
+        except RuntimeError:
+            host = torch.empty(a.shape, dtype=tdt)
+        host.numpy().view(a.dtype)[...] = a                          # one read of the mapped file
+        return host.to(device, non_blocking=True)
+
     def get_raw_yuv_block(self, first, last, device):
         """Frames [first, last) of both files as flat device tensors + the cvvdp_yuv_format describing them."""
-        out = []
-        for vr in (self.test_vidr, self.reference_vidr):
-            a = vr.raw_frames(self.offset + first, self.offset + last)
-            tdt = torch.int16 if a.dtype == np.uint16 else torch.uint8   # torch has no uint16: keep the bit pattern
-            try:
-                host = torch.empty(a.shape, dtype=tdt, pin_memory=True)   # page-locked staging: the H2D copy is asynchronous
-            except RuntimeError:
-                host = torch.empty(a.shape, dtype=tdt)
-            host.numpy().view(a.dtype)[...] = a                          # one read of the mapped file
-            out.append(host.to(device, non_blocking=True))
+        out = [self._upload(vr, first, last, device) for vr in (self.test_vidr, self.reference_vidr)]
         fmt = _capi.YuvFormat()
         fmt.chroma, fmt.bit_depth, fmt.matrix = int(self.test_vidr.chroma_ss), int(self.test_vidr.bit_depth), int(self.test_vidr.color_space)
         fmt.frame_stride_test, fmt.frame_stride_ref = self.test_vidr.frame_pixels, self.reference_vidr.frame_pixels
         return out[0], out[1], fmt
+
+    def get_raw_yuv_side(self, side, first, last, device):
+        """Frames [first, last) of the test (side 0) or reference (1) file: (codes, format, width, height) -- for the resize path,
+        where the two files may differ in size and format."""
+        vr = self.reference_vidr if side else self.test_vidr
+        fmt = _capi.YuvFormat()
+        fmt.chroma, fmt.bit_depth, fmt.matrix = int(vr.chroma_ss), int(vr.bit_depth), int(vr.color_space)
+        fmt.frame_stride_test = fmt.frame_stride_ref = vr.frame_pixels
+        return self._upload(vr, first, last, device), fmt, vr.width, vr.height

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CVVDP_ABI_VERSION 7
+#define CVVDP_ABI_VERSION 8
 #define CVVDP_MAX_FILTER_LEN 65 /* 0.25 s at up to 256 fps, cvvdp_metric.py:1059 */
 #define CVVDP_MAX_LEVELS 16
 #define CVVDP_MAX_WINDOW 256    /* filter_len - 1 + frames per block */
@@ -166,6 +166,17 @@ typedef struct cvvdp_yuv_format {
 int cvvdp_process_block_yuv(cvvdp_handle* h, const void* dev_test, const void* dev_ref, const cvvdp_yuv_format* fmt,
                             int32_t raw_first, const int32_t* hist_src, int32_t n_frames, int32_t q_frame_offset,
                             void* stream);
+
+/* full_screen_resize of .yuv sources (video_source_yuv.py:266-284 constructor, :333-336 in _get_frame): n_frames Y'CbCr frames of
+ * src_width x src_height (layout and fmt as for cvvdp_process_block_yuv; is_ref selects fmt->frame_stride_ref) are unpacked to
+ * display-encoded R'G'B' (YUVReader.get_frame_rgb_tensor, :147-170), resized with
+ * torch.nn.functional.interpolate(size=(dst_height, dst_width), mode=...) semantics (align_corners False, no antialiasing) and
+ * clipped to [0,1].  dev_rgb receives fp32 [3][n_frames][dst_height][dst_width] = a [1,3,n,H,W] block for cvvdp_process_block
+ * (CVVDP_F32); dev_tmp is scratch for 3*n_frames*src_height*src_width floats.  Needs no configured clip. */
+enum { CVVDP_RESIZE_NEAREST = 0, CVVDP_RESIZE_BILINEAR = 1, CVVDP_RESIZE_BICUBIC = 2, CVVDP_RESIZE_AREA = 3 };
+int cvvdp_unpack_yuv_resized(cvvdp_handle* h, const void* dev_codes, const cvvdp_yuv_format* fmt, int32_t is_ref, int32_t src_width,
+                             int32_t src_height, int32_t n_frames, int32_t dst_width, int32_t dst_height, int32_t mode, float* dev_tmp,
+                             float* dev_rgb, void* stream);
 
 /* Sources that deliver temporally pre-filtered channels (vid_source.is_temporally_filtered, cvvdp_metric.py:470-488):
  * frames are fp32 [B, 4, n, H, W] in colour space 'DKLd65_trans' (Y-sustained, RG, YV, Y-transient; element strides in

@@ -107,3 +107,70 @@ def clip_to_rgb(samples, props, n_frames):
         Y, u, v = split_frame(samples, f, H, W, props["chroma_ss"])
         out[0, :, f] = frame_to_rgb(Y, u, v, props["bit_depth"], props["chroma_ss"], props["color_space"]).transpose(2, 0, 1)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# full_screen_resize (video_source_yuv.py:333-336): torch.nn.functional.interpolate(size=..., mode=...) with its defaults
+# (align_corners False, no antialiasing), restated from ATen/native/UpSample.h in float32, then clip to [0,1].
+
+def _src_index(n_out, n_in, cubic):
+    scale = np.float32(n_in) / np.float32(n_out)                         # area_pixel_compute_scale
+    src = scale * (np.arange(n_out, dtype=np.float32) + np.float32(0.5)) - np.float32(0.5)
+    return src if cubic else np.maximum(src, np.float32(0))              # area_pixel_compute_source_index
+
+
+def _cubic_weights(t):
+    A = np.float32(-0.75)
+    def c1(x):
+        return ((A + 2) * x - (A + 3)) * x * x + 1
+    def c2(x):
+        return ((A * x - 5 * A) * x + 8 * A) * x - 4 * A
+    return [c2(t + 1), c1(t), c1(1 - t), c2(2 - t)]
+
+
+def _resize_axis(x, n_out, mode, axis):
+    x = np.moveaxis(x, axis, -1).astype(np.float32)
+    n_in = x.shape[-1]
+    if mode == "nearest":                                                # nearest_neighbor_compute_source_index
+        idx = np.minimum(np.floor(np.arange(n_out, dtype=np.float32) * (np.float32(n_in) / np.float32(n_out))).astype(np.int64), n_in - 1)
+        y = x[..., idx]
+    elif mode == "bilinear":
+        src = _src_index(n_out, n_in, False)
+        i0 = src.astype(np.int64)
+        i1 = i0 + (i0 < n_in - 1)
+        l1 = (src - i0.astype(np.float32)).astype(np.float32)
+        y = (np.float32(1) - l1) * x[..., i0] + l1 * x[..., i1]
+    elif mode == "bicubic":
+        src = _src_index(n_out, n_in, True)
+        fl = np.floor(src)
+        w = _cubic_weights((src - fl).astype(np.float32))
+        i = fl.astype(np.int64)
+        y = sum(x[..., np.clip(i - 1 + k, 0, n_in - 1)] * w[k].astype(np.float32) for k in range(4))
+    elif mode == "area":                                                 # adaptive average pooling: start / end index
+        o = np.arange(n_out, dtype=np.int64)
+        a, b = (o * n_in) // n_out, -((-(o + 1) * n_in) // n_out)
+        y = np.stack([x[..., a[k]:b[k]].sum(-1, dtype=np.float32) for k in range(n_out)], -1)
+        return np.moveaxis(y.astype(np.float32), -1, axis), (b - a)
+    else:
+        raise ValueError(mode)
+    return np.moveaxis(y.astype(np.float32), -1, axis)
+
+
+def resize_planes(x, height, width, mode):
+    """[..., Hs, Ws] float32 -> [..., height, width], clipped to [0,1] (both separable passes in float32: rows of taps along x first,
+    then along y, like ATen's bilinear / bicubic kernels; area divides the window sum by its pixel count)."""
+    if mode == "area":
+        y, nx = _resize_axis(x, width, mode, -1)
+        y, ny = _resize_axis(y, height, mode, -2)
+        y = y / (ny[:, None] * nx[None, :]).astype(np.float32)
+    else:
+        y = _resize_axis(_resize_axis(x, width, mode, -1), height, mode, -2)
+    return np.clip(y, 0.0, 1.0).astype(np.float32)
+
+
+def clip_to_rgb_resized(samples, props, n_frames, height, width, mode):
+    """clip_to_rgb followed by the reference's per-frame resize; a clip that already has the target size is left alone (:333)."""
+    rgb = clip_to_rgb(samples, props, n_frames)
+    if (props["height"], props["width"]) == (height, width):
+        return rgb
+    return resize_planes(rgb, height, width, mode)

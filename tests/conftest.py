@@ -22,12 +22,17 @@ def _names(pattern):
 
 def golden_cases():
     """Array-input cases made by oracle/make_goldens.py."""
-    return [n for n in _names("*.npz") if n != "setup" and not n.startswith(("yuv", "fullsize", "kat_", "bench_", "outputs", "features"))]
+    return [n for n in _names("*.npz") if n != "setup" and not n.startswith(("yuv", "fullsize", "kat_", "bench_", "outputs", "features", "resize_"))]
 
 
 def yuv_cases():
     """Planar Y'CbCr file cases made by oracle/make_goldens_yuv.py."""
     return _names("yuv*.npz")
+
+
+def resize_cases():
+    """.yuv pairs with full_screen_resize, made by oracle/make_goldens_resize.py."""
+    return _names("resize_*.npz")
 
 
 def load_golden(name):

@@ -32,7 +32,7 @@ def test_arguments_mirror_the_reference():
 
 def test_refusals_need_no_gpu(tmp_path, capsys):
     from colorvideovdp_amd import cli as rc
-    for extra in (["--device", "cpu"], ["--temp-padding", "valid"], ["--temp-resample"], ["--full-screen-resize", "bilinear"]):
+    for extra in (["--device", "cpu"], ["--temp-padding", "valid"], ["--temp-resample"], ["--dump-channels", "lpyr"]):
         assert rc.main(["-t", "a.png", "-r", "b.png"] + extra) == 1          # vq_exception -> logged, exit code 1
     assert rc.main([]) == 0                                                   # "Paths to both ... need to be specified", like the reference
     img = (np.arange(64 * 48 * 3).reshape(48, 64, 3) % 251).astype(np.uint8)

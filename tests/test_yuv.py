@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, yuv_cases
+from conftest import load_golden, resize_cases, yuv_cases
 
 from oracle import yuv_oracle as yo
 
@@ -165,8 +165,8 @@ def test_hip_yuv_errors(tmp_path):
     from colorvideovdp_amd import _capi
     g = load_golden("yuv422_8b_709_64x40x5_24")
     ft, fr = _write(g, str(tmp_path))
-    with pytest.raises(NotImplementedError):
-        cv.video_source_yuv_file(ft, fr, full_screen_resize="bilinear", resize_resolution=(32, 20))
+    with pytest.raises(RuntimeError):
+        cv.video_source_yuv_file(ft, fr, full_screen_resize="bilinear")          # no resize_resolution
     vs = cv.video_source_yuv_file(ft, fr, display_photometry="standard_4k")
     with pytest.raises(NotImplementedError):
         vs.get_test_frame(0, torch.device("cuda"))
@@ -180,3 +180,115 @@ def test_hip_yuv_errors(tmp_path):
         setattr(f2, field, bad)
         assert lib.cvvdp_process_block_yuv(met._handle, t.data_ptr(), r.data_ptr(), ctypes.byref(f2), 0, hist, 2, 0, 0) < 0
         assert lib.cvvdp_last_error(met._handle)
+
+
+# ------------------------------------------------------------------ full_screen_resize (video_source_yuv.py:266-284, 333-336)
+def _side_props(g, side):
+    return yo.decode_video_props(str(g["fname_" + side]))
+
+
+@pytest.mark.parametrize("name", resize_cases())
+def test_oracle_resize_matches_reference(name):
+    """The oracle's restatement of torch.nn.functional.interpolate against the frames the reference handed to its display model,
+    and the whole oracle on the resized clips against the reference's JOD."""
+    from oracle.cvvdp_oracle import Oracle
+    g = load_golden(name)
+    H, W, F, mode = int(g["height"]), int(g["width"]), int(g["frames"]), str(g["mode"])
+    clips = {}
+    for side in ("test", "ref"):
+        clips[side] = yo.clip_to_rgb_resized(g[side], _side_props(g, side), F, H, W, mode)
+        assert clips[side].shape == (1, 3, F, H, W)
+        assert np.abs(clips[side][0, :, 0] - g[f"rgb_{side}_first"]).max() <= 2e-6
+    jod, stats = Oracle(display_name=str(g["display"])).predict(clips["test"], clips["ref"], dim_order="BCFHW", frames_per_second=float(g["fps"]))
+    assert abs(float(jod) - float(g["jod"])) <= 1e-4
+    np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("mode", ["nearest", "bilinear", "bicubic", "area"])
+def test_resize_restatement_is_torch_interpolate(mode):
+    rng = np.random.default_rng(len(mode))
+    for hs, ws, hd, wd in ((13, 17, 29, 40), (40, 31, 17, 12), (8, 8, 8, 16), (7, 9, 21, 5), (30, 30, 30, 30)):
+        x = rng.random((2, hs, ws)).astype(np.float32) * 1.2 - 0.1
+        want = torch.nn.functional.interpolate(torch.tensor(x)[None], size=(hd, wd), mode=mode)[0].clip(0.0, 1.0).numpy()
+        assert np.abs(yo.resize_planes(x, hd, wd, mode) - want).max() <= 3e-6
+
+
+def test_resized_source_geometry(tmp_path):
+    from colorvideovdp_amd.video_source_yuv import video_source_yuv_file
+    g = load_golden("resize_bicubic_down_up_420_8b")                     # test 72x40, reference 36x20
+    ft, fr = _write(g, str(tmp_path))
+    with pytest.raises(RuntimeError):
+        video_source_yuv_file(ft, fr)                                    # different sizes need a resize
+    vs = video_source_yuv_file(ft, fr, full_screen_resize="bicubic", resize_resolution=(54, 30))
+    assert vs.get_video_size() == [30, 54, int(g["frames"])] and vs.needs_resize()
+    vs = video_source_yuv_file(ft, ft, full_screen_resize="bicubic", resize_resolution=(72, 40))
+    assert not vs.needs_resize()                                         # already at the target size: the fused path, like the reference (:333)
+    vs = video_source_yuv_file(ft, ft, full_screen_resize="bilinear", resize_resolution=(200, 50), retain_aspect_ratio=True)
+    assert vs.get_video_size()[:2] == [50, 90]                           # keeps 72:40 inside 200x50 (:273-282)
+    vs = video_source_yuv_file(ft, ft, full_screen_resize="bilinear", resize_resolution=(90, 200), retain_aspect_ratio=True)
+    assert vs.get_video_size()[:2] == [50, 90]
+    with pytest.raises(RuntimeError):
+        video_source_yuv_file(ft, ft, full_screen_resize="lanczos", resize_resolution=(72, 40))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", resize_cases())
+def test_hip_resize_matches_reference(name, tmp_path):
+    """cvvdp_unpack_yuv_resized against the reference's resized frames, then the whole metric on the resized source."""
+    import ctypes
+    import colorvideovdp_amd as cv
+    from colorvideovdp_amd import _capi
+    g = load_golden(name)
+    H, W, F, mode, disp = int(g["height"]), int(g["width"]), int(g["frames"]), str(g["mode"]), str(g["display"])
+    ft, fr = _write(g, str(tmp_path))
+    vs = cv.video_source_yuv_file(ft, fr, display_photometry=disp, full_screen_resize=mode, resize_resolution=(W, H))
+    assert list(vs.get_video_size()) == [H, W, F]
+    met = cv.cvvdp(display_name=disp)
+    lib = _capi.lib()
+    for side in range(2):
+        codes, fmt, sw, sh = vs.get_raw_yuv_side(side, 0, 2, met.device)
+        tmp = torch.empty(3 * 2 * sh * sw, dtype=torch.float32, device=met.device)
+        rgb = torch.full((3, 2, H, W), -1.0, dtype=torch.float32, device=met.device)
+        m = _capi.RESIZE_MODES[mode] if (sw, sh) != (W, H) else _capi.RESIZE_MODES["nearest"]
+        rc = lib.cvvdp_unpack_yuv_resized(met._handle, codes.data_ptr(), ctypes.byref(fmt), side, sw, sh, 2, W, H, m, tmp.data_ptr(), rgb.data_ptr(),
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _capi.check(met._handle, rc, "cvvdp_unpack_yuv_resized")
+        want = g["rgb_test_first" if side == 0 else "rgb_ref_first"]
+        assert np.abs(rgb[:, 0].cpu().numpy() - want).max() <= 3e-6
+        p = _side_props(g, "ref" if side else "test")
+        np.testing.assert_allclose(rgb[:, 1].cpu().numpy(), yo.clip_to_rgb_resized(g["ref" if side else "test"], p, 2, H, W, mode)[0, :, 1], atol=3e-6, rtol=0)
+    jod, stats = met.predict_video_source(vs)
+    assert abs(float(jod) - float(g["jod"])) <= JOD_TOL
+    np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
+    # blocks of one frame: same frames, same result
+    _, s1 = cv.cvvdp(display_name=disp, block_frames=1).predict_video_source(vs)
+    np.testing.assert_array_equal(s1["Q_per_ch"], stats["Q_per_ch"])
+
+
+@pytest.mark.gpu
+def test_hip_resize_through_the_command_line_and_errors(tmp_path, capsys):
+    import ctypes
+    import colorvideovdp_amd as cv
+    from colorvideovdp_amd import _capi, cli as rc
+    g = load_golden("resize_bilinear_up_420_8b")
+    ft, fr = _write(g, str(tmp_path))
+    E_ARG = -1   # CVVDP_E_ARG, include/cvvdp_hip.h
+    # -f resizes to the display's resolution (run_cvvdp.py:308-309): standard_fhd = 1920x1080
+    assert rc.main(["-t", ft, "-r", fr, "-d", "standard_fhd", "-f", "bilinear", "--temp-padding", "replicate", "-q"]) == 0
+    got = float(capsys.readouterr().out.strip())
+    vs = cv.video_source_yuv_file(ft, fr, display_photometry="standard_fhd", full_screen_resize="bilinear", resize_resolution=(1920, 1080))
+    want, stats = cv.cvvdp(display_name="standard_fhd").predict_video_source(vs)
+    assert stats["width"] == 1920 and stats["height"] == 1080 and f"{got:.4f}" == f"{want.item():.4f}"
+    # a source already at the target size goes the fused route and gives what it gives without the option
+    vs_same = cv.video_source_yuv_file(ft, fr, display_photometry="standard_fhd", full_screen_resize="bicubic", resize_resolution=(48, 32))
+    _, s_a = cv.cvvdp(display_name="standard_fhd").predict_video_source(vs_same)
+    _, s_b = cv.cvvdp(display_name="standard_fhd").predict_video_source(cv.video_source_yuv_file(ft, fr, display_photometry="standard_fhd"))
+    np.testing.assert_array_equal(s_a["Q_per_ch"], s_b["Q_per_ch"])
+    met = cv.cvvdp(display_name="standard_fhd")
+    lib = _capi.lib()
+    codes, fmt, sw, sh = vs.get_raw_yuv_side(0, 0, 1, met.device)
+    buf = torch.empty(3 * 64 * 96, dtype=torch.float32, device=met.device)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.cvvdp_unpack_yuv_resized(met._handle, codes.data_ptr(), ctypes.byref(fmt), 0, sw, sh, 1, 96, 64, 7, buf.data_ptr(), buf.data_ptr(), st) == E_ARG
+    assert lib.cvvdp_unpack_yuv_resized(met._handle, codes.data_ptr(), ctypes.byref(fmt), 0, sw + 1, sh, 1, 96, 64, 1, buf.data_ptr(), buf.data_ptr(), st) == E_ARG
+    assert lib.cvvdp_unpack_yuv_resized(met._handle, None, ctypes.byref(fmt), 0, sw, sh, 1, 96, 64, 1, buf.data_ptr(), buf.data_ptr(), st) == E_ARG

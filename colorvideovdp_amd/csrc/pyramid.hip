@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
 // row.  Horizontal-then-vertical is the same linear operator as the reference's vertical-then-
 // horizontal (the two passes act on different axes); only fp32 rounding order differs (~1e-7).
 constexpr int RSEG = 32;  // output rows per thread
+typedef float v4f_ __attribute__((ext_vector_type(4)));
 
 // 5-tap dot product with a FIXED operation order.  The marching kernels evaluate the same taps from several inlined
 // copies of their row code (prologue / steady state); left to the compiler, each copy may contract a*b + c*d + ...
@@ -106,7 +107,12 @@ __device__ __forceinline__ void hreduce_row(const ReduceArgs& a, const float* im
       const float mx = (x >= 0 && x < a.W) ? 1.0f : 0.0f;
       t.x *= mx; t.y *= mx; t.z *= mx; t.w *= mx;
     } else {
+#ifdef R2_NT_LOADS
+      const v4f_ q4 = __builtin_nontemporal_load(reinterpret_cast<const v4f_*>(row + x));
+      t = make_float4(q4.x, q4.y, q4.z, q4.w);
+#else
       t = *reinterpret_cast<const float4*>(row + x);
+#endif
     }
     v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
   }
@@ -299,7 +305,11 @@ __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
           for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaf(w0[3][j], k4, o[j]);
         }
       }
+#ifndef R2_PLAIN_STORES   // level l+1 is next read by a later kernel, long after it left the L2: streaming stores (-1 % on the 4K level-0 pass)
+      if (own && y1 >= 2 * r2a && y1 < 2 * r2b) __builtin_nontemporal_store(v4f_{o[0], o[1], o[2], o[3]}, reinterpret_cast<v4f_*>(out1 + (int64_t)y1 * a.W1 + c1));
+#else
       if (own && y1 >= 2 * r2a && y1 < 2 * r2b) *reinterpret_cast<float4*>(out1 + (int64_t)y1 * a.W1 + c1) = make_float4(o[0], o[1], o[2], o[3]);
+#endif
     } else {
       cold = true;
     }

@@ -53,5 +53,11 @@ for k in range(n):
         msg += f"  heat frac>2e-3 {(d > 2e-3).mean():.1e} max {d.max():.1e}"
         ok = ok and (d > 2e-3).mean() < 1e-3 and d.max() < 2e-2
     print(("ok  " if ok else "BAD ") + msg, flush=True)
+    if not ok:                                         # keep the case for a closer look (oracle / reference / HIP side by side)
+        import os
+        os.makedirs("gpurun_out/fuzz_bad", exist_ok=True)
+        tt, rr = (x.numpy() if torch.is_tensor(x) else x for x in (test, ref))
+        np.savez_compressed(f"gpurun_out/fuzz_bad/seed{seed}_case{k}.npz", test=tt, ref=rr, fps=fps, display=disp, padding=pad, heat=str(heat),
+                            q_hip=s["Q_per_ch"], q_oracle=os_["Q_per_ch"], jod_hip=float(np.atleast_1d(j.cpu().numpy())[0]))
     bad += not ok
 print("bad:", bad)

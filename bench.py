@@ -191,6 +191,9 @@ def main():
     ap.add_argument("--workload", default="4k64", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default=None, choices=["f32", "u8", "yuv420p8", "yuv420p10"], help="input sample format (default: the workload's)")
     ap.add_argument("--heatmap", default=None, choices=["none", "raw", "threshold", "supra-threshold"], help="default: the workload's")
+    ap.add_argument("--heatmap-format", default="u8", choices=["u8", "f16"],
+                    help="what the heat-map sink takes: the writers' 8-bit RGB frames made on the GPU (3 B/pixel over PCIe, the default: "
+                         "what a heat-map video / PNG sequence needs) or the reference's fp16 planes (6 B/pixel)")
     ap.add_argument("--distogram", action="store_true", help="also write the distogram of the last step (default for 8k256pq)")
     ap.add_argument("--gen", default=None, choices=["cpu", "gpu"], help="frame generator (default: cpu when a reference fixture exists for the clip)")
     ap.add_argument("--frames", type=int, default=None, help="override the workload's frame count (per GPU or total)")
@@ -245,7 +248,7 @@ def main():
         clip = ResidentClip(n_total, lo, first + count, H, W, fps, dtype, device, gen=gen, pq_range=args.workload == "8k256pq")
     if world > 1:
         m.set_frame_sharding("world")
-    sink = HeatmapFrameMeans() if heat is not None else None      # the heat map leaves the GPU block by block (bounded host memory)
+    sink = HeatmapFrameMeans(uint8=args.heatmap_format == "u8") if heat is not None else None      # the heat map leaves the GPU block by block (bounded host memory)
 
     def step():
         return m.predict_video_source(clip, heatmap_sink=sink) if sink is not None else m.predict_video_source(clip)
@@ -342,6 +345,7 @@ def main():
         out["kernel_ms_per_step"]["sum"] = round(tot / args.steps, 3)
     if sink is not None:
         out["heatmap_frames_streamed_per_step"] = sink.frames_seen // (args.steps + args.warmup)
+        out["config"]["heatmap_sink_format"] = "uint8 RGB frames (as written to .mp4 / .png), 3 B/pixel D2H" if sink.wants_uint8 else "fp16 planes, 6 B/pixel D2H"
     if distogram:
         try:
             path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"bench_distogram_{args.workload}.png")

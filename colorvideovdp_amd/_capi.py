@@ -92,6 +92,7 @@ SYMBOLS = {
     "cvvdp_get_q_per_ch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvvdp_pool_jod": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "cvvdp_get_heatmap": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "cvvdp_get_heatmap_rgb8": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "cvvdp_debug_buffer": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "cvvdp_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "cvvdp_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

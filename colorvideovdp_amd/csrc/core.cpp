@@ -619,7 +619,14 @@ int cvvdp_pool_jod(cvvdp_handle* h, const float* q, int32_t B, int32_t C, int32_
   return check_launch(h, "pool");
 }
 
+static int get_heatmap_impl(cvvdp_handle* h, int32_t n_frames, void* dev_out_f16, int out_u8, void* stream);
 int cvvdp_get_heatmap(cvvdp_handle* h, int32_t n_frames, void* dev_out_f16, void* stream) {
+  return get_heatmap_impl(h, n_frames, dev_out_f16, 0, stream);
+}
+int cvvdp_get_heatmap_rgb8(cvvdp_handle* h, int32_t n_frames, void* dev_out_u8, void* stream) {
+  return get_heatmap_impl(h, n_frames, dev_out_u8, 1, stream);
+}
+static int get_heatmap_impl(cvvdp_handle* h, int32_t n_frames, void* dev_out_f16, int out_u8, void* stream) {
   if (!h || !h->ws) return fail(h, CVVDP_E_STATE, "no workspace bound");
   if (h->c.heatmap == CVVDP_HEATMAP_NONE) return fail(h, CVVDP_E_STATE, "heat map not enabled");
   if (!dev_out_f16 || n_frames < 1 || n_frames * h->c.batch != h->last_items) return fail(h, CVVDP_E_ARG, "n_frames does not match the last block");
@@ -631,7 +638,7 @@ int cvvdp_get_heatmap(cvvdp_handle* h, int32_t n_frames, void* dev_out_f16, void
   a.jod_a = h->p.jod_a; a.jod_exp = h->p.jod_exp;
   a.stats = reinterpret_cast<uint32_t*>(h->ws + h->hstats_off);
   a.curve = h->ws + h->hcurve_off;
-  a.out = dev_out_f16;
+  a.out = dev_out_f16; a.out_u8 = out_u8;
   ProfScope ps(h, CVVDP_PROF_HEATMAP, s);
   if (h->c.heatmap == CVVDP_HEATMAP_RAW) {
     launch_heat_raw(a, s);

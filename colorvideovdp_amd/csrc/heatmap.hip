@@ -16,10 +16,17 @@ __device__ __forceinline__ float heat_value(float q, float jod_a, float jod_exp)
   return 1.0f - jod / 10.0f;
 }
 
+// the 8-bit frame the reference's writers make of the fp16 map: (clip(x, 0, 1) * 255).astype(uint8)  (run_cvvdp.py:62-76 via np.clip at :78)
+__device__ __forceinline__ uint8_t half_to_u8(__half v) {
+  return (uint8_t)(fminf(fmaxf(__half2float(v), 0.0f), 1.0f) * 255.0f);
+}
+
 __global__ __launch_bounds__(256) void k_heat_raw(HeatArgs a) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)a.items * a.P) return;
-  reinterpret_cast<__half*>(a.out)[i] = __float2half(heat_value(a.recon[i], a.jod_a, a.jod_exp));
+  const __half v = __float2half(heat_value(a.recon[i], a.jod_a, a.jod_exp));
+  if (a.out_u8) reinterpret_cast<uint8_t*>(a.out)[i] = half_to_u8(v);    // [items][P][1]
+  else reinterpret_cast<__half*>(a.out)[i] = v;
 }
 
 void launch_heat_raw(const HeatArgs& a, hipStream_t s) {
@@ -152,7 +159,9 @@ __global__ __launch_bounds__(256) void k_heat_colour(HeatArgs a) {
   for (int c = 0; c < 3; ++c) {
     const float col = a.cch[lo * 3 + c] * (1.0f - fr) + a.cch[hi * 3 + c] * fr;
     const float c16 = __half2float(__float2half(col));                     // colour map is stored as fp16 first (:96-98)
-    out[((int64_t)c * a.items + item) * a.P + i] = __float2half(fminf(fmaxf(c16 * tmo, 0.0f), 1.0f));
+    const __half v = __float2half(fminf(fmaxf(c16 * tmo, 0.0f), 1.0f));
+    if (a.out_u8) reinterpret_cast<uint8_t*>(a.out)[((int64_t)item * a.P + i) * 3 + c] = half_to_u8(v);   // interleaved RGB frames
+    else out[((int64_t)c * a.items + item) * a.P + i] = v;
   }
 }
 

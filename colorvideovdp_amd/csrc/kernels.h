@@ -210,7 +210,8 @@ struct HeatArgs {
   float jod_a, jod_exp;
   uint32_t* stats;        // per item kHeatStatsWords words: [0] min positive y (bits), [1] max y (bits), [4..) histogram
   float* curve;           // per item 1024 tone-curve values + [1024]=b_min, [1025]=b_max, [1026]=flag(1: histogram curve)
-  void* out;              // fp16 [ch][items][P]
+  void* out;              // fp16 [ch][items][P], or (out_u8) uint8 [items][P][ch]
+  int32_t out_u8;
   int32_t n_nodes;        // colour map nodes (5 threshold, 3 supra-threshold)
   float cin[5];           // node positions
   float cch[15];          // node colours / luminance, [node][rgb]  (visualize_diff_map.py:93-94)

@@ -211,7 +211,9 @@ class cvvdp(vq_metric):
 
         heatmap_sink (extension): callable(first_frame, frames) that receives the heat map block by block
         (`frames`: float16 CPU tensor [1, 1|3, n, H, W], valid only during the call) instead of `stats["heatmap"]`
-        holding the whole clip -- an 8K x 256-frame colour heat map is 51 GB.  See colorvideovdp_amd.heatmap_writers."""
+        holding the whole clip -- an 8K x 256-frame colour heat map is 51 GB.  A sink with an attribute `wants_uint8 = True`
+        receives the frames as its file format needs them: uint8 [n, H, W, 1|3], converted on the GPU exactly as the reference's
+        writers convert the fp16 map (run_cvvdp.py:62-78).  See colorvideovdp_amd.heatmap_writers."""
         inner = getattr(vid_source, "vs", None)             # video_source_file wraps the source that does the work (video_source_file.py:755-820)
         if isinstance(inner, video_source):
             vid_source = inner
@@ -474,9 +476,12 @@ class cvvdp(vq_metric):
         if self.do_heatmap and heatmap_sink is not None:
             # Streaming: two page-locked staging buffers of one block each; block k is handed to the sink while
             # the kernels of block k+1 run.  Host memory is bounded by 2 blocks whatever the clip length.
+            # A sink that writes 8-bit frames anyway (PNG, ffmpeg) sets `wants_uint8`: the conversion the reference's writers do on
+            # the host is then done by the heat-map kernel, and 3 instead of 6 bytes per pixel cross PCIe
             nb_max = 1 if is_image else clip.block_frames
+            sink_u8 = bool(getattr(heatmap_sink, "wants_uint8", False))
             stage = getattr(self, "_hm_stage", None)
-            if stage is None or stage[0].numel() < hm_ch * nb_max * height * width:
+            if stage is None or stage[0].numel() < hm_ch * nb_max * height * width:       # (fp16 elements: enough for either format)
                 stage = self._hm_stage = [torch.empty(hm_ch * nb_max * height * width, dtype=torch.float16, device="cpu", pin_memory=True) for _ in range(2)]
             copy_stream = getattr(self, "_hm_stream", None) or torch.cuda.Stream(self.device)
             self._hm_stream = copy_stream
@@ -508,15 +513,22 @@ class cvvdp(vq_metric):
                 heatmap_sink(frame0, view)
 
         def fetch_heatmap(ff, n):
-            buf = torch.empty((hm_ch, n, height, width), dtype=torch.float16, device=self.device)
-            _capi.check(self._handle, lib.cvvdp_get_heatmap(self._handle, n, buf.data_ptr(), stream), "cvvdp_get_heatmap")
+            if stage is not None and sink_u8:
+                buf = torch.empty((n, height, width, hm_ch), dtype=torch.uint8, device=self.device)
+                _capi.check(self._handle, lib.cvvdp_get_heatmap_rgb8(self._handle, n, buf.data_ptr(), stream), "cvvdp_get_heatmap_rgb8")
+            else:
+                buf = torch.empty((hm_ch, n, height, width), dtype=torch.float16, device=self.device)
+                _capi.check(self._handle, lib.cvvdp_get_heatmap(self._handle, n, buf.data_ptr(), stream), "cvvdp_get_heatmap")
             if stage is not None:
                 flush_sink(keep=1)                         # the buffer about to be overwritten has been consumed
                 dst = stage[1] if (pending_sink and pending_sink[0][3] == 0) else stage[0]
-                view = dst[:hm_ch * n * height * width].view(1, hm_ch, n, height, width)
+                if sink_u8:
+                    view = dst.view(torch.uint8)[:hm_ch * n * height * width].view(n, height, width, hm_ch)
+                else:
+                    view = dst[:hm_ch * n * height * width].view(1, hm_ch, n, height, width)
                 copy_stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(copy_stream):
-                    view[0].copy_(buf, non_blocking=True)
+                    (view if sink_u8 else view[0]).copy_(buf, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(copy_stream)
                 buf.record_stream(copy_stream)

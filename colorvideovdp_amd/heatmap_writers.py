@@ -15,10 +15,15 @@ import shutil
 import subprocess
 
 import numpy as np
+import torch
 
 
 def heatmap_to_uint8(frames):
-    """[1, C, n, H, W] fp16 in [0,1] -> [n, H, W, 3] uint8, the conversion of run_cvvdp.py:np2vid / np2img (:62-76)."""
+    """[1, C, n, H, W] fp16 in [0,1] -> [n, H, W, 3] uint8, the conversion of run_cvvdp.py:np2vid / np2img (:62-76).
+    Frames that arrive as uint8 [n, H, W, C] (a sink with wants_uint8: the GPU has done exactly this) pass through."""
+    if frames.dtype == torch.uint8:
+        a = frames.numpy()
+        return np.concatenate([a] * 3, -1) if a.shape[-1] == 1 else a
     a = frames[0].permute(1, 2, 3, 0).float().numpy()            # [n, H, W, C]
     if a.shape[-1] == 1:
         a = np.concatenate([a] * 3, -1)
@@ -27,6 +32,8 @@ def heatmap_to_uint8(frames):
 
 class HeatmapPngWriter:
     """One 8-bit PNG per frame: `pattern % frame_index`, e.g. "out/clip_heatmap_%05d.png" (needs Pillow)."""
+
+    wants_uint8 = True          # frames arrive as uint8 [n, H, W, C], converted on the GPU
 
     def __init__(self, pattern):
         if "%" not in pattern:
@@ -52,6 +59,8 @@ class HeatmapVideoWriter:
     """The reference's heat-map video (run_cvvdp.py:44-66 np2vid): raw rgb24 frames piped into `ffmpeg`, mpeg4 codec at
     qscale 3, the clip's frame rate.  The process is started with the first block (the frame size is known then) and
     closed by close(); `available()` tells whether an ffmpeg executable exists on this machine."""
+
+    wants_uint8 = True          # frames arrive as uint8 [n, H, W, C], converted on the GPU
 
     def __init__(self, path, fps, verbose=False, ffmpeg=None):
         self.path, self.fps, self.verbose = path, fps, verbose
@@ -112,13 +121,17 @@ class HeatmapFrameMeans:
     """Keeps only a per-frame mean of every colour plane, taken over every `step`-th pixel in both directions (a cheap sink
     for benchmarks and tests: the host only touches 1/step^2 of the 6 bytes per pixel that crossed PCIe)."""
 
-    def __init__(self, step=16):
+    def __init__(self, step=16, uint8=False):
         self.step = step
+        self.wants_uint8 = uint8          # take the frames as a file writer would (uint8 [n, H, W, C]); means are then of the 8-bit codes / 255
         self.means = {}
         self.frames_seen = 0
 
     def __call__(self, first_frame, frames):
-        m = frames[0, :, :, ::self.step, ::self.step].float().mean(dim=(2, 3)).numpy()           # [C, n]
+        if frames.dtype == torch.uint8:
+            m = (frames[:, ::self.step, ::self.step].float().mean(dim=(1, 2)) / 255.0).numpy().T      # [C, n]
+        else:
+            m = frames[0, :, :, ::self.step, ::self.step].float().mean(dim=(2, 3)).numpy()           # [C, n]
         for i in range(m.shape[1]):
             self.means[first_frame + i] = m[:, i].copy()
         self.frames_seen += m.shape[1]

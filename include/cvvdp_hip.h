@@ -206,6 +206,10 @@ int cvvdp_pool_jod(cvvdp_handle* h, const float* dev_q_per_ch, int32_t B, int32_
  * (cvvdp_metric.py:724-744) and visualize_diff_map (visualize_diff_map.py:48-106, tone-mapped per
  * frame = block of 1, the reference's CPU behaviour).  Output fp16 [channels(1|3), n_frames, H, W]. */
 int cvvdp_get_heatmap(cvvdp_handle* h, int32_t n_frames, void* dev_out_f16, void* stream);
+/* The same frames as the reference's file writers encode them (np2vid / np2img, run_cvvdp.py:44-78): the fp16 value clipped to
+ * [0,1], times 255, truncated.  Output uint8 [n_frames, H, W, channels(1|3)] (interleaved RGB): 3 instead of 6 bytes per pixel
+ * to bring to the host, and nothing left to convert there. */
+int cvvdp_get_heatmap_rgb8(cvvdp_handle* h, int32_t n_frames, void* dev_out_u8, void* stream);
 
 /* Test/inspection: device pointer + element count of an internal buffer (level where relevant). */
 int cvvdp_debug_buffer(cvvdp_handle* h, int32_t which, int32_t level, void** dev_ptr, size_t* n_floats);

@@ -588,6 +588,46 @@ def test_streaming_heatmap_sink_matches_the_whole_clip_tensor(tmp_path):
         _metric(dict(meta, heatmap=None)).predict_video_source(vs, heatmap_sink=sink)
 
 
+def test_uint8_heatmap_sink_is_the_writers_conversion(tmp_path):
+    """A sink with wants_uint8 receives [n, H, W, C] uint8 frames made on the GPU (cvvdp_get_heatmap_rgb8): bit for bit what the
+    reference's writers make of the fp16 map (np.clip(x, 0, 1) * 255 -> uint8, run_cvvdp.py:62-78); half the bytes over PCIe."""
+    import colorvideovdp_amd as cv
+    from colorvideovdp_amd import heatmap_writers as hw
+    from PIL import Image
+    g = load_golden("vid_u8_135x240x18_60_fhd_raw")
+    meta = dict(g["meta"])
+    t, r = _inputs(g)
+    for mode in ("raw", "threshold", "supra-threshold"):
+        meta["heatmap"] = mode
+        m = _metric(meta, block_frames=7)
+        _, s_full = m.predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+        want = hw.heatmap_to_uint8(s_full["heatmap"])                      # the host conversion of the fp16 tensor: [F, H, W, 3]
+        C = 1 if mode == "raw" else 3
+        got = np.zeros(want.shape[:3] + (C,), np.uint8)
+
+        class Sink:
+            wants_uint8 = True
+
+            def __call__(self, first, frames):
+                assert frames.dtype == torch.uint8 and frames.shape[1:] == got.shape[1:]
+                got[first:first + frames.shape[0]] = frames.numpy()
+
+        vs = cv.video_source_array(t, r, meta["fps"], dim_order=meta["dim_order"], display_photometry=m.display_photometry)
+        _, stats = m.predict_video_source(vs, heatmap_sink=Sink())
+        assert "heatmap" not in stats
+        np.testing.assert_array_equal(np.concatenate([got] * 3, -1) if C == 1 else got, want)
+        np.testing.assert_array_equal(stats["Q_per_ch"], s_full["Q_per_ch"])
+    png = hw.HeatmapPngWriter(str(tmp_path / "hm_%02d.png"))
+    m.predict_video_source(vs, heatmap_sink=png)
+    assert png.frames_written == want.shape[0]
+    np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "hm_11.png")), want[11])
+    means8, means16 = hw.HeatmapFrameMeans(step=4, uint8=True), hw.HeatmapFrameMeans(step=4)
+    m.predict_video_source(vs, heatmap_sink=means8)
+    m.predict_video_source(vs, heatmap_sink=means16)
+    assert means8.frames_seen == means16.frames_seen == want.shape[0]
+    assert max(np.abs(means8.means[f] - means16.means[f]).max() for f in means8.means) < 1.0 / 255
+
+
 @pytest.mark.parametrize("W", [241, 242, 243, 244, 245, 246, 247, 248, 249, 250, 251, 252, 253, 254, 255, 341, 342, 483, 484, 683])
 def test_ragged_widths_against_oracle(W):
     """every width takes the marching reduce and the fused band kernel (W % 8 in 1..7, odd and even, the

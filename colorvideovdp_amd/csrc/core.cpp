@@ -636,6 +636,7 @@ static int get_heatmap_impl(cvvdp_handle* h, int32_t n_frames, void* dev_out_f16
   a.ctx = h->ws + h->lv[0].g_off;  // plane 0 = test Y-sustained (cvvdp_metric.py:400)
   a.P = (int)h->lv[0].P; a.items = h->last_items; a.mode = h->c.heatmap;
   a.jod_a = h->p.jod_a; a.jod_exp = h->p.jod_exp;
+  a.jod_lin = h->p.jod_a * powf(0.1f, h->p.jod_exp - 1.0f);
   a.stats = reinterpret_cast<uint32_t*>(h->ws + h->hstats_off);
   a.curve = h->ws + h->hcurve_off;
   a.out = dev_out_f16; a.out_u8 = out_u8;

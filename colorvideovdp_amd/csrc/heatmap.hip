@@ -122,46 +122,105 @@ __device__ __forceinline__ float scale_node(int i, float bmin, float bmax, float
   return (i < 512) ? bmin + step * (float)i : bmax - step * (float)(1023 - i);
 }
 
-__global__ __launch_bounds__(256) void k_heat_colour(HeatArgs a) {
-  const int item = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.P) return;
-  const uint32_t* st = a.stats + (int64_t)item * kHeatStatsWords;
-  const float* cv = a.curve + (int64_t)item * kHeatCurveWords;
-  const float clampval = __uint_as_float(st[0]);
-  const float bmin = cv[1024], bmax = cv[1025];
-  const float b = log_lum(a.ctx[(int64_t)item * a.P + i], clampval);
+// met2jod for the per-pixel map (cvvdp_metric.py:646-658, :744) with the hardware log2 / exp2 pair instead of powf: the map leaves
+// as fp16 (or 8 bit), 1e-6 relative is far below its last bit; the slope of the linear part is a host constant (a.jod_lin)
+__device__ __forceinline__ float heat_value_fast(float q, const HeatArgs& a) {
+  const float jod = q <= 0.1f ? 10.0f - a.jod_lin * q : 10.0f - a.jod_a * fast_pow(q, a.jod_exp);
+  return 1.0f - jod * 0.1f;
+}
+
+// One pixel of visualize_diff_map (visualize_diff_map.py:48-106): tone-mapped context luminance x colour-coded difference.
+struct HeatPixelCtx {
+  float clampval, bmin, bmax, step, inv_step, inv_lin;
+  bool lin;
+  const float* cv;
+};
+__device__ __forceinline__ void heat_pixel(const HeatArgs& a, const HeatPixelCtx& h, float y, float q, __half (&out)[3]) {
+  const float b = fast_log2(fmaxf(y, h.clampval)) * 0.6931471805599453f;
   float tmo;
-  if (cv[1026] == 0.0f) {
-    tmo = (b - bmin) / (bmax - bmin + 1e-3f) * 0.6f + 0.2f;               // visualize_diff_map.py:28-31
+  if (h.lin) {
+    tmo = (b - h.bmin) * h.inv_lin * 0.6f + 0.2f;                          // visualize_diff_map.py:28-31
   } else {
-    const float step = (bmax - bmin) / 1023.0f;
-    int hi = (int)ceilf((b - bmin) / step);
+    int hi = (int)ceilf((b - h.bmin) * h.inv_step);
     hi = min(max(hi, 0), 1023);
-    while (hi > 0 && scale_node(hi - 1, bmin, bmax, step) >= b) --hi;     // bucketize: smallest node >= b
-    while (hi < 1023 && scale_node(hi, bmin, bmax, step) < b) ++hi;
+    while (hi > 0 && scale_node(hi - 1, h.bmin, h.bmax, h.step) >= b) --hi;     // bucketize: smallest node >= b
+    while (hi < 1023 && scale_node(hi, h.bmin, h.bmax, h.step) < b) ++hi;
     const int lo = max(hi - 1, 0);
-    const float xl = scale_node(lo, bmin, bmax, step), xh = scale_node(hi, bmin, bmax, step);
-    float fr = (b - xl) / (xh - xl + 0.000001f);
+    const float xl = scale_node(lo, h.bmin, h.bmax, h.step), xh = scale_node(hi, h.bmin, h.bmax, h.step);
+    float fr = (b - xl) * fast_rcp(xh - xl + 0.000001f);
     if (hi == lo || fr < 0.0f) fr = 0.0f;
-    tmo = cv[lo] * (1.0f - fr) + cv[hi] * fr;
+    tmo = h.cv[lo] * (1.0f - fr) + h.cv[hi] * fr;
   }
-  const float d = fminf(fmaxf(heat_value(a.recon[(int64_t)item * a.P + i], a.jod_a, a.jod_exp), 0.0f), 1.0f);
+  const float d = fminf(fmaxf(heat_value_fast(q, a), 0.0f), 1.0f);
   int hi = a.n_nodes;
   for (int k = a.n_nodes - 1; k >= 0; --k)
     if (a.cin[k] >= d) hi = k;
   hi = min(hi, a.n_nodes - 1);
   const int lo = max(hi - 1, 0);
-  float fr = (d - a.cin[lo]) / (a.cin[hi] - a.cin[lo] + 0.000001f);
+  float fr = (d - a.cin[lo]) * fast_rcp(a.cin[hi] - a.cin[lo] + 0.000001f);
   if (hi == lo || fr < 0.0f) fr = 0.0f;
-  __half* out = reinterpret_cast<__half*>(a.out);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float col = a.cch[lo * 3 + c] * (1.0f - fr) + a.cch[hi * 3 + c] * fr;
     const float c16 = __half2float(__float2half(col));                     // colour map is stored as fp16 first (:96-98)
-    const __half v = __float2half(fminf(fmaxf(c16 * tmo, 0.0f), 1.0f));
-    if (a.out_u8) reinterpret_cast<uint8_t*>(a.out)[((int64_t)item * a.P + i) * 3 + c] = half_to_u8(v);   // interleaved RGB frames
-    else out[((int64_t)c * a.items + item) * a.P + i] = v;
+    out[c] = __float2half(fminf(fmaxf(c16 * tmo, 0.0f), 1.0f));
+  }
+}
+
+// VEC: P % 4 == 0 -- a thread owns 4 adjacent pixels (16-byte loads, 8-byte fp16 / 12-byte RGB8 stores); otherwise one pixel.
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_heat_colour(HeatArgs a) {
+  const int item = blockIdx.y;
+  constexpr int N = VEC ? 4 : 1;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * N;
+  if (i >= a.P) return;
+  const uint32_t* st = a.stats + (int64_t)item * kHeatStatsWords;
+  HeatPixelCtx h;
+  h.cv = a.curve + (int64_t)item * kHeatCurveWords;
+  h.clampval = __uint_as_float(st[0]);
+  h.bmin = h.cv[1024]; h.bmax = h.cv[1025];
+  h.lin = h.cv[1026] == 0.0f;
+  h.step = (h.bmax - h.bmin) / 1023.0f;
+  h.inv_step = 1.0f / h.step;
+  h.inv_lin = 1.0f / (h.bmax - h.bmin + 1e-3f);
+  const int64_t base = (int64_t)item * a.P + i;
+  float y[N], q[N];
+  if constexpr (VEC) {
+    const float4 yv = *reinterpret_cast<const float4*>(a.ctx + base), qv = *reinterpret_cast<const float4*>(a.recon + base);
+    y[0] = yv.x; y[1] = yv.y; y[2] = yv.z; y[3] = yv.w;
+    q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+  } else {
+    y[0] = a.ctx[base]; q[0] = a.recon[base];
+  }
+  __half px[N][3];
+#pragma unroll
+  for (int k = 0; k < N; ++k) heat_pixel(a, h, y[k], q[k], px[k]);
+  if (a.out_u8) {                                                          // interleaved RGB frames
+    uint8_t* o = reinterpret_cast<uint8_t*>(a.out) + base * 3;
+    if constexpr (VEC) {
+      uint32_t w[3] = {0u, 0u, 0u};
+#pragma unroll
+      for (int e = 0; e < 12; ++e) w[e >> 2] |= (uint32_t)half_to_u8(px[e / 3][e % 3]) << (8 * (e & 3));
+      uint32_t* o32 = reinterpret_cast<uint32_t*>(o);                      // (item*P + i)*3 bytes: a multiple of 12
+      o32[0] = w[0]; o32[1] = w[1]; o32[2] = w[2];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] = half_to_u8(px[0][c]);
+    }
+  } else {
+    __half* out = reinterpret_cast<__half*>(a.out);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      __half* o = out + ((int64_t)c * a.items + item) * a.P + i;
+      if constexpr (VEC) {
+        union { __half hv[4]; uint2 u; } pk;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pk.hv[k] = px[k][c];
+        *reinterpret_cast<uint2*>(o) = pk.u;
+      } else {
+        o[0] = px[0][c];
+      }
+    }
   }
 }
 
@@ -171,7 +230,8 @@ void launch_heat_colour(const HeatArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_heat_range, dim3(gx, a.items), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_heat_hist, dim3(gx, a.items), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_heat_curve, dim3(a.items), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_heat_colour, dim3((a.P + 255) / 256, a.items), dim3(256), 0, s, a);
+  if (a.P % 4 == 0) hipLaunchKernelGGL(k_heat_colour<true>, dim3((a.P / 4 + 255) / 256, a.items), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_heat_colour<false>, dim3((a.P + 255) / 256, a.items), dim3(256), 0, s, a);
 }
 
 }  // namespace cvvdp

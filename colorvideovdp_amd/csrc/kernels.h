@@ -208,6 +208,7 @@ struct HeatArgs {
   const float* ctx;       // context image: test Y-sustained level-0 plane [items][P] (cvvdp_metric.py:400)
   int32_t P, items, mode;
   float jod_a, jod_exp;
+  float jod_lin;          // jod_a * 0.1^(jod_exp - 1): slope of met2jod's linear part (cvvdp_metric.py:652-655)
   uint32_t* stats;        // per item kHeatStatsWords words: [0] min positive y (bits), [1] max y (bits), [4..) histogram
   float* curve;           // per item 1024 tone-curve values + [1024]=b_min, [1025]=b_max, [1026]=flag(1: histogram curve)
   void* out;              // fp16 [ch][items][P], or (out_u8) uint8 [items][P][ch]

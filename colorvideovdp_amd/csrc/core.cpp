@@ -39,6 +39,8 @@ struct cvvdp_handle {
   float* ws = nullptr;
   int last_items = 0;
   std::string err;
+  float eotf_tab[256];          // per-code display model of 8-bit sources (eotf_table), made once in cvvdp_create
+  bool eotf_tab_ok = false;
   bool prof = false;
   std::vector<ProfEvent> events;
   size_t events_used = 0;
@@ -260,11 +262,13 @@ void cvvdp_struct_sizes(int32_t* params_bytes, int32_t* clip_bytes) {
   if (clip_bytes) *clip_bytes = (int32_t)sizeof(cvvdp_clip);
 }
 
+static bool eotf_table(const cvvdp_params& p, float scale, float lin_lo, float (&tab)[256]);
 int cvvdp_create(const cvvdp_params* params, cvvdp_handle** out) {
   if (!params || !out) return CVVDP_E_ARG;
   cvvdp_handle* h = new (std::nothrow) cvvdp_handle();
   if (!h) return CVVDP_E_ARG;
   h->p = *params;
+  h->eotf_tab_ok = eotf_table(h->p, (float)((double)h->p.Y_peak - (double)h->p.Y_black), std::max(0.005f, h->p.Y_black), h->eotf_tab);
   *out = h;
   return CVVDP_OK;
 }
@@ -385,6 +389,56 @@ int cvvdp_bind_workspace(cvvdp_handle* h, void* dev, size_t bytes) {
   return CVVDP_OK;
 }
 
+// Emitted light of one channel for an 8-bit code: the per-channel part of vvdp_display_photo_eotf.forward
+// (display_model.py:333-365; srgb2lin :78-80, pq2lin :58-70) on V = code / 255 (video_source.py:320-346), evaluated once per code
+// in fp32 with the reference's operation order (separate roundings: every intermediate is a float variable; libm's powf
+// stands where torch.pow stands).  HLG mixes the channels (its OOTF gain depends on the pixel's luminance): no table.
+static bool eotf_table(const cvvdp_params& p, float scale, float lin_lo, float (&tab)[256]) {
+  static const bool off = getenv("CVVDP_NO_EOTF_LUT") && atoi(getenv("CVVDP_NO_EOTF_LUT")) != 0;   // A/B hook
+  if (off) return false;
+  if (p.eotf != CVVDP_EOTF_SRGB && p.eotf != CVVDP_EOTF_PQ && p.eotf != CVVDP_EOTF_LINEAR && p.eotf != CVVDP_EOTF_GAMMA) return false;
+  auto clip = [](float x, float lo, float hi) { return std::min(std::max(x, lo), hi); };
+  for (int code = 0; code < 256; ++code) {
+    const volatile float V = (float)code / 255.0f;
+    volatile float L;
+    if (p.eotf == CVVDP_EOTF_SRGB) {
+      volatile float lin;
+      if (V > 0.04045f) { const volatile float x = (V + 0.055f) / 1.055f; lin = powf(x, 2.4f); }
+      else lin = V / 12.92f;
+      if (p.exposure != 1.0f) { const volatile float e = lin * p.exposure; lin = clip(e, 0.0f, 1.0f); }
+      const volatile float a = scale * lin;
+      const volatile float b = a + p.Y_black;
+      L = b + p.Y_refl;
+    } else if (p.eotf == CVVDP_EOTF_PQ) {
+      const float m = (float)(1.0 / 78.843750000000000), n = (float)(1.0 / 0.15930175781250000);
+      const float c1 = 0.83593750000000000f, c2 = 18.851562500000000f, c3 = 18.687500000000000f;
+      const volatile float t = powf(V, m);
+      const volatile float num = std::max(t - c1, 0.0f);
+      const volatile float ct = c3 * t;
+      const volatile float den = c2 - ct;
+      const volatile float r = num / den;
+      const volatile float pw = powf(r, n);
+      const volatile float lin = 10000.0f * pw;
+      const volatile float e = lin * p.exposure;
+      const volatile float c = clip(e, 0.005f, p.Y_peak);
+      const volatile float b = c + p.Y_black;
+      L = b + p.Y_refl;
+    } else if (p.eotf == CVVDP_EOTF_LINEAR) {
+      const volatile float e = V * p.exposure;
+      const volatile float c = clip(e, lin_lo, p.Y_peak);
+      L = c + p.Y_refl;
+    } else {
+      const volatile float g = powf(V, p.gamma);
+      const volatile float e = g * p.exposure;
+      const volatile float a = scale * clip(e, 0.0f, 1.0f);
+      const volatile float b = a + p.Y_black;
+      L = b + p.Y_refl;
+    }
+    tab[code] = L;
+  }
+  return true;
+}
+
 static void fill_display(const cvvdp_handle* h, DisplayArgs& d) {
   d.eotf = h->p.eotf; d.channels = h->c.channels;
   d.Y_peak = h->p.Y_peak; d.Y_black = h->p.Y_black; d.Y_refl = h->p.Y_refl;
@@ -393,6 +447,8 @@ static void fill_display(const cvvdp_handle* h, DisplayArgs& d) {
   d.lin_lo = std::max(0.005f, h->p.Y_black);
   d.hlg_c = (float)(0.5 - 0.17883277 * std::log(4.0 * 0.17883277));
   for (int i = 0; i < 9; ++i) d.m[i] = h->p.rgb2dkl[i];
+  d.use_lut = h->eotf_tab_ok ? 1 : 0;
+  if (h->eotf_tab_ok) std::memcpy(d.lut, h->eotf_tab, sizeof(d.lut));
 }
 
 int cvvdp_put_image(cvvdp_handle* h, const void* t, const void* r, int32_t dtype, const int64_t st[5], const int64_t sr[5], void* stream) {

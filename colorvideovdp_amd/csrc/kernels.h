@@ -30,6 +30,10 @@ struct DisplayArgs {         // display model, shared by the image and the fused
   float lin_lo;             // max(0.005, Y_black) for the linear EOTF
   float hlg_c;              // 0.5 - a*ln(4a)
   float m[9];               // RGB -> DKL
+  // 8-bit sources, per-channel EOTFs (sRGB, PQ, gamma, linear): code -> emitted light of one channel, the whole per-channel part of
+  // display_model.py:333-365 evaluated by the host once per code (core.cpp eotf_table) with the reference's fp32 operation order
+  int32_t use_lut;
+  float lut[256];
 };
 struct PhotoArgs {
   const void* src[2];     // test, ref

@@ -8,6 +8,8 @@ namespace cvvdp {
 
 template <int DT, int V>
 __global__ __launch_bounds__(256) void k_photometry(PhotoArgs a) {
+  __shared__ float s_tab[DT == CVVDP_U8 ? 256 : 1];
+  const bool use_lut = stage_eotf_table<DT>(a.dm, s_tab);
   const int pv = blockIdx.x * 256 + threadIdx.x;
   const int P = a.H * a.W;
   const int pix = pv * V;
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(256) void k_photometry(PhotoArgs a) {
     if constexpr (DT == CVVDP_F32_DKL) {
       o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
     } else {
-      pixel_to_dkl(a.dm, v, o);
+      pixel_to_dkl(a.dm, v, o, s_tab, use_lut);
     }
     out[0][i] = o[0]; out[1][i] = o[1]; out[2][i] = o[2];
   }

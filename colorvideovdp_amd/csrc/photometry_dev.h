@@ -43,10 +43,28 @@ __device__ __forceinline__ float pq2lin(float v) {
 
 __device__ __forceinline__ float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
-// display model + colour transform of one pixel; v = display-encoded RGB (or 1 channel replicated)
-__device__ __forceinline__ void pixel_to_dkl(const DisplayArgs& a, float (&v)[3], float (&o)[3]) {
+// 8-bit sources: the table of DisplayArgs::lut staged in LDS (256 floats; a per-lane gather from kernel arguments would be a
+// global load queued behind the prefetched frames).  Returns whether the table is in use (kernel-uniform).
+template <int DT>
+__device__ __forceinline__ bool stage_eotf_table(const DisplayArgs& dm, float* s_tab) {
+  if constexpr (DT == CVVDP_U8) {
+    if (dm.use_lut) {
+      for (int i = threadIdx.x; i < 256; i += blockDim.x) s_tab[i] = dm.lut[i];
+      __syncthreads();
+      return true;
+    }
+  }
+  return false;
+}
+
+// display model + colour transform of one pixel; v = display-encoded RGB (or 1 channel replicated); lut: see stage_eotf_table
+__device__ __forceinline__ void pixel_to_dkl(const DisplayArgs& a, float (&v)[3], float (&o)[3], const float* lut = nullptr, bool use_lut = false) {
   float L[3];
   const int e = a.eotf;
+  if (use_lut) {                 // v = code * (1/255) within an ulp: the code is recovered exactly
+#pragma unroll
+    for (int c = 0; c < 3; ++c) L[c] = lut[(int)(v[c] * 255.0f + 0.5f)];
+  } else {
   if (e != CVVDP_EOTF_LINEAR) {  // display_model.py:335-337 (clamp is a no-op when nothing is out of range)
 #pragma unroll
     for (int c = 0; c < 3; ++c) v[c] = clipf(v[c], 0.0f, 1.0f);
@@ -82,6 +100,7 @@ __device__ __forceinline__ void pixel_to_dkl(const DisplayArgs& a, float (&v)[3]
   } else {  // gamma
 #pragma unroll
     for (int c = 0; c < 3; ++c) L[c] = a.scale * clipf(fast_pow(v[c], a.gamma) * a.exposure, 0.0f, 1.0f) + a.Y_black + a.Y_refl;
+  }
   }
   if (a.channels == 3) {
 #pragma unroll

@@ -89,7 +89,8 @@ __device__ __forceinline__ void yuv_pixel_rgb(const YuvArgs& q, const YuvCtx& cx
 }
 
 template <int DT, int V>
-__device__ __forceinline__ void convert_pixels(const FirArgs& a, const PixCtx<DT>& cx, const Raw<DT, V>& in, float (&dkl)[3][V]) {
+__device__ __forceinline__ void convert_pixels(const FirArgs& a, const PixCtx<DT>& cx, const Raw<DT, V>& in, float (&dkl)[3][V],
+                                               const float* lut = nullptr, bool use_lut = false) {
   if constexpr (is_yuv(DT)) {
     float v[3];
     yuv_pixel_rgb(a.yuv, cx, in, v);
@@ -103,7 +104,7 @@ __device__ __forceinline__ void convert_pixels(const FirArgs& a, const PixCtx<DT
       if constexpr (DT == CVVDP_F32_DKL) {
         o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
       } else {
-        pixel_to_dkl(a.dm, v, o);
+        pixel_to_dkl(a.dm, v, o, lut, use_lut);
       }
       dkl[0][i] = o[0]; dkl[1][i] = o[1]; dkl[2][i] = o[2];
     }
@@ -125,6 +126,8 @@ __device__ __forceinline__ void load_f32_run(const float* p, float (&v)[V]) {
 
 template <int DT, int FL, int V>
 __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
+  __shared__ float s_tab[DT == CVVDP_U8 ? 256 : 1];
+  const bool use_lut = stage_eotf_table<DT>(a.dm, s_tab);
   const int pix = (blockIdx.x * 256 + threadIdx.x) * V;
   if (pix >= a.P) return;
   const int b = blockIdx.y, side = blockIdx.z;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
         Raw<DT, V> in;
         float d[3][V];
         load_pixels<DT, V>(a, cx, side, off0 + e * sf, in);
-        convert_pixels<DT, V>(a, cx, in, d);
+        convert_pixels<DT, V>(a, cx, in, d, s_tab, use_lut);
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
       const int fi = f0 + u;
       if (fi < a.n_frames) {     // uniform
         float d[3][V];
-        convert_pixels<DT, V>(a, cx, pf[0], d);
+        convert_pixels<DT, V>(a, cx, pf[0], d, s_tab, use_lut);
 #pragma unroll
         for (int q = 0; q + 1 < PF; ++q) pf[q] = pf[q + 1];
         if (fi + PF < a.n_frames) load_pixels<DT, V>(a, cx, side, off0 + (int64_t)(a.raw_first + fi + PF) * sf, pf[PF - 1]);
@@ -235,6 +238,8 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
 // the window costs 51 VGPRs: 5-6 waves per SIMD hide the HBM latency this kernel is bound by.
 template <int DT, int FL>
 __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
+  __shared__ float s_tab[DT == CVVDP_U8 ? 256 : 1];
+  const bool use_lut = stage_eotf_table<DT>(a.dm, s_tab);
   static_assert(FL >= 3 && FL <= 17, "window = one 16-wide register vector + the newest frame in a scalar slot");
   typedef float v16f __attribute__((ext_vector_type(16)));
   const int pix = blockIdx.x * 256 + threadIdx.x;
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
     if (e >= 0) {
       Raw<DT, 1> in;
       load_pixels<DT, 1>(a, cx, side, off0 + e * sf, in);
-      convert_pixels<DT, 1>(a, cx, in, d);
+      convert_pixels<DT, 1>(a, cx, in, d, s_tab, use_lut);
     } else {
       for (int p = 0; p < 3; ++p) d[p][0] = hist[p * a.h_plane + (int64_t)(-1 - e) * a.h_slot];
     }
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         float d[3][1];
-        convert_pixels<DT, 1>(a, cx, pf[u], d);
+        convert_pixels<DT, 1>(a, cx, pf[u], d, s_tab, use_lut);
         load_pixels<DT, 1>(a, cx, side, off0 + (int64_t)(a.raw_first + min(fw + u + PF, a.n_frames - 1)) * sf, pf[u]);
         const int sw = __builtin_amdgcn_readfirstlane(sA == 0 ? M - 1 : sA - 1);
 #pragma unroll
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
 #define CVVDP_FIR_FRAME(FI, Q)                                                                                   \
   {                                                                                                              \
     float d[3][1];                                                                                               \
-    convert_pixels<DT, 1>(a, cx, pf[Q], d);                                                                          \
+    convert_pixels<DT, 1>(a, cx, pf[Q], d, s_tab, use_lut);                                                                          \
     load_pixels<DT, 1>(a, cx, side, off0 + (int64_t)(a.raw_first + min((FI) + PF, a.n_frames - 1)) * sf, pf[Q]);    \
     const int sw = __builtin_amdgcn_readfirstlane(sA == 0 ? M - 1 : sA - 1);   /* (A-1) mod M, in an SGPR */      \
     _Pragma("unroll") for (int p = 0; p < 3; ++p) { wlo[p][sw] = whi[p]; whi[p] = d[p][0]; }                     \
@@ -350,6 +355,8 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
 // Any filter length (odd frame rates): no register window; every tap re-reads and re-converts its frame.
 template <int DT>
 __global__ __launch_bounds__(256) void k_fir_generic(FirArgs a) {
+  __shared__ float s_tab[DT == CVVDP_U8 ? 256 : 1];
+  const bool use_lut = stage_eotf_table<DT>(a.dm, s_tab);
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= a.P) return;
   const int item = blockIdx.y, side = blockIdx.z;
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(256) void k_fir_generic(FirArgs a) {
     if (e >= 0) {
       Raw<DT, 1> in;
       load_pixels<DT, 1>(a, cx, side, off0 + e * a.sf[side], in);
-      convert_pixels<DT, 1>(a, cx, in, d);
+      convert_pixels<DT, 1>(a, cx, in, d, s_tab, use_lut);
     } else {
       for (int p = 0; p < 3; ++p) d[p][0] = hist[p * a.h_plane + (int64_t)(-1 - e) * a.h_slot];
     }
@@ -378,6 +385,8 @@ __global__ __launch_bounds__(256) void k_fir_generic(FirArgs a) {
 // tail of the block -> history, for the generic path (the fused kernel does this itself)
 template <int DT>
 __global__ __launch_bounds__(256) void k_hist_generic(FirArgs a, float* tmp) {
+  __shared__ float s_tab[DT == CVVDP_U8 ? 256 : 1];
+  const bool use_lut = stage_eotf_table<DT>(a.dm, s_tab);
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= a.P) return;
   const int k = blockIdx.y % (a.fl - 1), b = blockIdx.y / (a.fl - 1), side = blockIdx.z;
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(256) void k_hist_generic(FirArgs a, float* tmp) {
   if (e >= 0) {
     Raw<DT, 1> in;
     load_pixels<DT, 1>(a, cx, side, off0 + e * a.sf[side], in);
-    convert_pixels<DT, 1>(a, cx, in, d);
+    convert_pixels<DT, 1>(a, cx, in, d, s_tab, use_lut);
   } else {
     for (int p = 0; p < 3; ++p) d[p][0] = hist[p * a.h_plane + (int64_t)(-1 - e) * a.h_slot];
   }

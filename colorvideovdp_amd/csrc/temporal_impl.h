@@ -312,6 +312,11 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
   // One frame: convert prefetch slot Q, refill it with frame fi+PF, FIR, store.  The refill is unconditional (the
   // last PF frames re-read the last frame) and the frame loop is unrolled PF times with static prefetch slots, so
   // no register copies touch values still in flight and the compiler can wait with exact vmcnt(N) counts.
+#ifdef CVVDP_FIR_PLAIN_STORES
+#define CVVDP_FIR_STORE(v, p) (*(p) = (v))
+#else
+#define CVVDP_FIR_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
 #define CVVDP_FIR_FRAME(FI, Q)                                                                                   \
   {                                                                                                              \
     float d[3][1];                                                                                               \
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
       float acc = 0.0f;                                                                                          \
       _Pragma("unroll") for (int s = 0; s < M; ++s) acc += wlo[p][s] * t[s];                                     \
       acc += whi[p] * a.taps_rot[c * CVVDP_ROT_TAPS + 32];                                                       \
-      __builtin_nontemporal_store(acc, &out[(int64_t)(2 * c + side) * a.o_plane + (int64_t)(FI) * o_item]);     \
+      CVVDP_FIR_STORE(acc, &out[(int64_t)(2 * c + side) * a.o_plane + (int64_t)(FI) * o_item]);                \
     }                                                                                                            \
     sA = (sA + 1 == M) ? 0 : sA + 1;                                                                             \
   }

@@ -33,12 +33,23 @@ __device__ __forceinline__ float srgb2lin(float p) {
   return p > 0.04045f ? x * x * fast_pow(x, 0.4f) : p * (1.0f / 12.92f);
 }
 
+// a product that is rounded on its own (hipcc contracts a*b +- c into an FMA by default)
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+#pragma clang fp contract(off)
+  const float p = a * b;
+  return p;
+}
+
 __device__ __forceinline__ float pq2lin(float v) {
   // display_model.py:58-70
   const float n = 0.15930175781250000f, m = 78.843750000000000f;
   const float c1 = 0.83593750000000000f, c2 = 18.851562500000000f, c3 = 18.687500000000000f;
-  float t = fast_pow(v, 1.0f / m);
-  return 10000.0f * fast_pow(fmaxf(t - c1, 0.0f) * fast_rcp(c2 - c3 * t), 1.0f / n);
+  const float t = fast_pow(v, 1.0f / m);
+  // c2 - c3*t cancels 18.85 - 18.5.. to ~0.2-0.3 and the quotient is raised to the power 6.28: the rounding of the product is
+  // visible in the result (2e-5).  torch rounds the product, then subtracts (two operations); hipcc would contract this into one FMA.
+  // With the product rounded on its own the mean distance to torch's CPU result drops from 1.05e-5 to 1.9e-6 (tools/ubench/pq_accuracy.*).
+  const float ct = mul_rounded(c3, t);
+  return 10000.0f * fast_pow(fmaxf(t - c1, 0.0f) * fast_rcp(c2 - ct), 1.0f / n);
 }
 
 __device__ __forceinline__ float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
@@ -104,7 +115,10 @@ __device__ __forceinline__ void pixel_to_dkl(const DisplayArgs& a, float (&v)[3]
   }
   if (a.channels == 3) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] = L[0] * a.m[3 * c] + L[1] * a.m[3 * c + 1] + L[2] * a.m[3 * c + 2];
+    // torch.sum(RGB * row, dim=channel) (display_model.py:268-269): three rounded products, summed left to right.  The opponent rows
+    // cancel for near-grey pixels, so whether a product is rounded (torch) or kept exact inside an FMA (hipcc's default contraction)
+    // shows in RG / YV: same operations as the reference here
+    for (int c = 0; c < 3; ++c) o[c] = (mul_rounded(L[0], a.m[3 * c]) + mul_rounded(L[1], a.m[3 * c + 1])) + mul_rounded(L[2], a.m[3 * c + 2]);
   } else {  // luminance-only content fills all three planes (cvvdp_metric.py:503 broadcast)
 #pragma unroll
     for (int c = 0; c < 3; ++c) o[c] = L[0];

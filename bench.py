@@ -310,6 +310,8 @@ def main():
             out["jod_reference"] = round(float(golden["jod"]), 5)
             out["jod_delta_vs_reference"] = float(abs(float(jod) - float(golden["jod"])))
             out["q_per_ch_max_rel_err_vs_reference"] = float(np.max(np.abs(q - qr) / (np.abs(qr) + 1e-6)))
+            # the parity tests' criterion (tests/test_gpu_parity.py: rtol 2e-4, atol 2e-6): 1.0 = at the tolerance
+            out["q_per_ch_max_err_over_test_tolerance"] = float(np.max(np.abs(q - qr) / (2e-4 * np.abs(qr) + 2e-6)))
             out["reference_fixture"] = f"tests/golden/{GOLDEN[(args.workload, dtype)]}.npz (the real reference on this very clip, oracle/make_goldens_bench.py)"
         else:
             out["jod_delta_vs_reference"] = None      # this torch build's CPU generator does not reproduce the fixture's frames

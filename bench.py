@@ -183,6 +183,28 @@ def cpu_baseline(W, H, fps, display, n_frames):
                 sample=f"first {n_frames} frames of the {W}x{H}@{fps} workload clip, oracle/cvvdp_oracle.py (torch CPU, block=1), {dt:.1f} s"), float(jod), t, r
 
 
+def lockstep_spinup(step, seconds, world, flag_device, sync=lambda: None):
+    """Untimed spin-up: run step() for about `seconds`, the SAME number of times on every rank.  Multi-rank, every step() ends in
+    a collective (the all-gather of Q_per_ch), so a per-rank clock must not decide when to stop: ranks enter the loop at different
+    times and would leave it after different iteration counts -- one rank then sits in barrier() while another is still in
+    all_gather, and the job hangs (round 2's bench did exactly that).  The ranks line up at a barrier first, and after every
+    step rank 0's clock decides for everybody (one broadcast word).  Returns the number of steps run."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        more = torch.tensor([1 if time.perf_counter() - t0 < seconds else 0], dtype=torch.int32, device=flag_device)
+        if world > 1:
+            dist.broadcast(more, src=0)
+        if int(more.item()) == 0:
+            return n
+        step()
+        sync()
+        n += 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,10 +279,10 @@ def main():
     # shader clock takes a few hundred milliseconds of load to come back up, far longer than W warm-up steps of 19 ms.  Measured
     # on a fresh box: the VALU-bound kernels ran 1.6-2x slower through the first ~7 steps.  So the device is first kept busy for
     # about a second (untimed, like the warm-up steps that follow).
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < float(os.environ.get("CVVDP_BENCH_SPINUP_S", "1.0")):
-        step()
-        torch.cuda.synchronize()
+    n_spin = lockstep_spinup(step, float(os.environ.get("CVVDP_BENCH_SPINUP_S", "1.0")), world,
+                             device if backend == "nccl" else torch.device("cpu"), torch.cuda.synchronize)
+    if sink is not None:
+        sink.frames_seen = 0          # count the streamed heat-map frames of the warm-up + timed steps only
     for _ in range(args.warmup):
         jod, stats = step()
     torch.cuda.synchronize()
@@ -302,7 +324,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": what, "name": args.workload, "frames_total": n_total, "frames_this_gpu": count, "input_dtype": dtype,
                    "heatmap": heat or "none", "frame_generator": gen, "block_frames": getattr(m, "last_block_frames", None)},
-        "jod": round(float(jod), 5),
+        "jod": round(float(jod), 5), "spinup_steps": n_spin,
     }
     if golden is not None and gen == "cpu":
         if (clip.checksum_test, clip.checksum_ref) == (int(golden["checksum_test"]), int(golden["checksum_ref"])):
@@ -347,6 +369,8 @@ def main():
         out["kernel_ms_per_step"]["sum"] = round(tot / args.steps, 3)
     if sink is not None:
         out["heatmap_frames_streamed_per_step"] = sink.frames_seen // (args.steps + args.warmup)
+        out["config"]["heatmap_sink"] = ("HeatmapFrameMeans: every frame crosses PCIe into page-locked memory, the host then reads 1/256 of "
+                                         "its pixels (a writer's encode / file cost is NOT in the figure)")
         out["config"]["heatmap_sink_format"] = "uint8 RGB frames (as written to .mp4 / .png), 3 B/pixel D2H" if sink.wants_uint8 else "fp16 planes, 6 B/pixel D2H"
     if distogram:
         try:

@@ -1,0 +1,42 @@
+"""bench.py's multi-rank path: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`
+must print its JSON line EVERY time.  Round 2's spin-up loop was timed per rank around a step that ends in a collective, so the
+ranks could leave it after different iteration counts and hang (3 of 5 runs).  Here: two ranks sharing the one GPU of the box
+(gloo rendezvous instead of RCCL, CVVDP_BENCH_DEVICE pins both ranks to device 0), both sharded workloads, five runs each, a
+hard 120 s limit per run.  The rank-count logic itself (same collective sequence on every rank) is covered on the CPU by
+tests/test_bench_spinup_cpu.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUNS = 5
+
+
+def _bench_two_ranks(extra, port):
+    env = dict(os.environ, CVVDP_BENCH_BACKEND="gloo", CVVDP_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", CVVDP_BENCH_SPINUP_S="0.5")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--cpu-frames", "0"] + extra
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("workload,extra,frames_total,scaling", [
+    ("4k64", [], 128, "weak"),                              # BASELINE.json's metric clip per GPU
+    ("4k1024", ["--frames", "256"], 256, "strong"),         # configs[3]'s shape (uint8, one clip split over the ranks), shortened
+])
+def test_two_rank_bench_prints_its_line_every_time(workload, extra, frames_total, scaling):
+    base = 29700 + (os.getpid() % 1500)
+    for i in range(RUNS):
+        d = _bench_two_ranks(["--workload", workload] + extra, base + i)
+        assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["config"]["frames_total"] == frames_total
+        assert d["value"] > 0 and 0 < d["jod"] <= 10
+        assert d["spinup_steps"] >= 1

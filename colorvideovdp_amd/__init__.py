@@ -7,4 +7,4 @@ from .video_source_file import load_image_as_array, video_source_file, video_sou
 from .video_source_yuv import video_source_yuv_file
 from .vq_metric import register_metric, vq_exception, vq_metric, vq_metric_dict
 
-__version__ = "0.1.0"
+__version__ = "0.3.0"

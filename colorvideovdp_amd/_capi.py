@@ -12,7 +12,7 @@ MAX_WINDOW = 256
 CSF_NODES = 32
 PROF_N = 6
 PROF_NAMES = ("photometry", "temporal_fir", "pyr_reduce", "band_level0", "band_rest", "heatmap")
-ABI_VERSION = 8
+ABI_VERSION = 9
 RESIZE_MODES = {"nearest": 0, "bilinear": 1, "bicubic": 2, "area": 3}   # CVVDP_RESIZE_*
 
 U8, U16, F16, F32, F32_DKL, YUV8, YUV16 = range(7)
@@ -71,6 +71,7 @@ class YuvFormat(C.Structure):
 
 SYMBOLS = {
     "cvvdp_abi_version": (C.c_int, []),
+    "cvvdp_build_flags": (C.c_int, []),
     "cvvdp_struct_sizes": (None, [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "cvvdp_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_void_p)]),
     "cvvdp_destroy": (None, [C.c_void_p]),
@@ -98,8 +99,11 @@ SYMBOLS = {
     "cvvdp_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
 }
 
-# CVVDP_LIB: development hook (kernel variants built side by side are benchmarked against each other); unset = the in-tree library
-LIB_PATH = os.environ.get("CVVDP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcvvdp_hip.so")
+# The product loads the in-tree library and nothing else.  Development only (tools/ab_bench.sh: kernel variants built side by
+# side are benchmarked against each other): CVVDP_LIB=<path> is honoured when CVVDP_DEV_KNOBS=1 is set as well.
+_IN_TREE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcvvdp_hip.so")
+LIB_PATH = (os.environ.get("CVVDP_LIB") if os.environ.get("CVVDP_DEV_KNOBS") == "1" else None) or _IN_TREE
+BUILD_DEV_KNOBS = 1
 _lib = None
 
 

@@ -39,7 +39,6 @@ struct cvvdp_handle {
   size_t ws_floats = 0;
   float* ws = nullptr;
   int last_items = 0;
-  std::string err;
   float eotf_tab[256];          // per-code display model of 8-bit sources (eotf_table), made once in cvvdp_create
   bool eotf_tab_ok = false;
   bool prof = false;
@@ -60,13 +59,16 @@ struct cvvdp_handle {
 
 namespace {
 
+thread_local std::string t_err;
+
 int fail(cvvdp_handle* h, int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  if (h) h->err = buf;
+  (void)h;
+  t_err = buf;      // per calling thread: a prefetch thread's cvvdp_unpack_yuv_resized and the main thread's calls share a handle
   return code;
 }
 
@@ -136,7 +138,7 @@ int run_pyramid_and_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, hip
   const int B = h->c.batch, items = n_frames * B, L = h->L, nch = h->nch;
   const float K[5] = {0.25f - 0.4f / 2.0f, 0.25f, 0.4f, 0.25f, 0.25f - 0.4f / 2.0f};  // lpyr_dec.py:179
   const int set = h->pipeline ? h->cur_set : 0;
-  static const bool fuse2 = !(getenv("CVVDP_REDUCE2") && atoi(getenv("CVVDP_REDUCE2")) == 0);   // tuning hook
+  static const bool fuse2 = dev_knob("CVVDP_REDUCE2", 1) != 0;
   for (int l = 0; l + 1 < L; ++l) {
     ProfScope ps(h, CVVDP_PROF_REDUCE, s);
     if (fuse2 && l + 2 < L && reduce2_supported(h->lv[l].H, h->lv[l].W)) {   // two levels per pass
@@ -181,8 +183,8 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
   // the heat bands, and before the next block overwrites the pyramid).  Same kernels, same arguments, same results: 4K image
   // 0.785 -> 0.61 ms, 1080p image 0.64 -> 0.50 ms, 854x480 x 64 frames 1.83 -> 1.69 ms.  Blocks whose level 0 is several GPU-fulls
   // keep the single stream: measured on 4K x 64, the overlap gains 0.1 ms of 19 and only makes the per-kernel timings overlap.
-  static const bool fork_env = !(getenv("CVVDP_BAND_STREAMS") && atoi(getenv("CVVDP_BAND_STREAMS")) == 0);
-  static const int fork_max = getenv("CVVDP_BAND_STREAMS_MAX") ? atoi(getenv("CVVDP_BAND_STREAMS_MAX")) : 1024;   // tuning hook
+  static const bool fork_env = dev_knob("CVVDP_BAND_STREAMS", 1) != 0;
+  static const int fork_max = dev_knob("CVVDP_BAND_STREAMS_MAX", 1024);
   bool fork = fork_env && L >= 4 && (int64_t)items * h->lv[0].n_strip * h->lv[0].n_seg <= fork_max;
   if (fork && !h->aux_stream[0]) {
     bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -322,7 +324,14 @@ void cvvdp_destroy(cvvdp_handle* h) {
   delete h;
 }
 
-const char* cvvdp_last_error(const cvvdp_handle* h) { return h ? h->err.c_str() : "null handle"; }
+const char* cvvdp_last_error(const cvvdp_handle* h) { return h ? t_err.c_str() : "null handle"; }
+int cvvdp_build_flags(void) {
+#ifdef CVVDP_DEV_KNOBS
+  return CVVDP_BUILD_DEV_KNOBS;
+#else
+  return 0;
+#endif
+}
 
 int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
   if (!h || !clip) return CVVDP_E_ARG;
@@ -363,8 +372,8 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
       // video: the nominal block is 64 frames, or the whole clip if that is shorter (total_frames is the same for every
       // block and shard of a clip); an image launch holds exactly `batch` items
       const int clip_frames = c.total_frames > 0 ? c.total_frames : 64;
-      static const int target_env = getenv("CVVDP_SEG_TARGET") ? atoi(getenv("CVVDP_SEG_TARGET")) : 0;       // tuning knobs (development)
-      static const int rows_env = getenv("CVVDP_SEG_ROWS") ? atoi(getenv("CVVDP_SEG_ROWS")) : 0;
+      static const int target_env = dev_knob("CVVDP_SEG_TARGET", 0);
+      static const int rows_env = dev_knob("CVVDP_SEG_ROWS", 0);
       const int nominal = c.is_video ? std::min(64, clip_frames) : 1, target = target_env > 0 ? target_env : 768;
       const int max_rows = rows_env > 0 ? rows_env : (c.is_video ? 384 : 256);
       const int per_seg = lv.n_strip * nominal * c.batch;
@@ -391,7 +400,7 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
   {
     // off by default: since the kernels were tuned, overlapping the band stage of block k with FIR + reduce of block
     // k+1 no longer gains anything (4K x 256: 84-87 ms either way) and costs a second pyramid set of workspace
-    static const bool pipe_env = getenv("CVVDP_PIPELINE") && atoi(getenv("CVVDP_PIPELINE")) != 0;
+    static const bool pipe_env = dev_knob("CVVDP_PIPELINE", 0) != 0;
     h->pipeline = pipe_env && c.is_video && c.heatmap == CVVDP_HEATMAP_NONE && !c.debug_dump && c.feature_size <= 0 && c.n_frames > c.block_frames;
     const size_t start = off;
     for (auto& lv : h->lv) { lv.g_off = off; off += align_up((size_t)2 * h->nch * h->items_cap * lv.P); }
@@ -431,7 +440,7 @@ int cvvdp_bind_workspace(cvvdp_handle* h, void* dev, size_t bytes) {
 // in fp32 with the reference's operation order (separate roundings: every intermediate is a float variable; libm's powf
 // stands where torch.pow stands).  HLG mixes the channels (its OOTF gain depends on the pixel's luminance): no table.
 static bool eotf_table(const cvvdp_params& p, float scale, float lin_lo, float (&tab)[256]) {
-  static const bool off = getenv("CVVDP_NO_EOTF_LUT") && atoi(getenv("CVVDP_NO_EOTF_LUT")) != 0;   // A/B hook
+  static const bool off = dev_knob("CVVDP_NO_EOTF_LUT", 0) != 0;
   if (off) return false;
   if (p.eotf != CVVDP_EOTF_SRGB && p.eotf != CVVDP_EOTF_PQ && p.eotf != CVVDP_EOTF_LINEAR && p.eotf != CVVDP_EOTF_GAMMA) return false;
   auto clip = [](float x, float lo, float hi) { return std::min(std::max(x, lo), hi); };

@@ -16,9 +16,12 @@ __device__ __forceinline__ float heat_value(float q, float jod_a, float jod_exp)
   return 1.0f - jod / 10.0f;
 }
 
-// the 8-bit frame the reference's writers make of the fp16 map: (clip(x, 0, 1) * 255).astype(uint8)  (run_cvvdp.py:62-76 via np.clip at :78)
+// the 8-bit frame the reference's writers make of the fp16 map: (clip(x, 0, 1) * 255.0).astype(uint8)  (run_cvvdp.py:59-63, :76).
+// The array is float16 and stays float16 under numpy's scalar promotion, so the product is ROUNDED TO HALF (step 0.125 in
+// [128, 256)) before the truncation: 4 % of all fp16 values in [0,1] land on another code than with an fp32 product.
 __device__ __forceinline__ uint8_t half_to_u8(__half v) {
-  return (uint8_t)(fminf(fmaxf(__half2float(v), 0.0f), 1.0f) * 255.0f);
+  const float p = fminf(fmaxf(__half2float(v), 0.0f), 1.0f) * 255.0f;   // exact in fp32 (11-bit x 8-bit significands)
+  return (uint8_t)__half2float(__float2half_rn(p));
 }
 
 __global__ __launch_bounds__(256) void k_heat_raw(HeatArgs a) {

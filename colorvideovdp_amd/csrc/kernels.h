@@ -10,6 +10,15 @@ namespace cvvdp {
 
 constexpr float kEps = 0.00001f;  // safe_pow epsilon, cvvdp_metric.py:83
 
+// Development knobs (A/B switches and tuning parameters read from the environment) exist only in a build made with
+// `make EXTRA=-DCVVDP_DEV_KNOBS`.  In the product build every knob is its compiled-in default: the library reads no
+// environment variable, so no stray setting can change the launch geometry (and with it the last bits of Q_per_ch).
+#ifdef CVVDP_DEV_KNOBS
+inline int dev_knob(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+constexpr int dev_knob(const char*, int dflt) { return dflt; }
+#endif
+
 // Transcendentals on the gfx950 SFU: v_log_f32 / v_exp_f32 / v_rcp_f32 are 1-ulp, quarter-rate
 // instructions.  pow(x,p) = exp2(p*log2(x)) has relative error ~ |p*log2 x| * 2^-24, i.e. <= 3e-6 over
 // the operand ranges of this metric (x in [1e-5, 1e3], p <= 3.7) -- three orders of magnitude inside the

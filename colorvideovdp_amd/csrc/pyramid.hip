@@ -361,7 +361,7 @@ void launch_reduce2(const Reduce2Args& a0, hipStream_t s) {
   const int nq = a.W1 / 4, waves = (nq + R2_LANES - 1) / R2_LANES, bx = (waves + 3) / 4;
   // equal row segments of at most R2_SEG rows (3 recomputed halo rows each), more of them when the launch would
   // otherwise have fewer than ~4096 blocks (small frames), down to 16 rows
-  static const int seg_cap = getenv("CVVDP_R2_SEG") ? std::max(4, atoi(getenv("CVVDP_R2_SEG"))) : R2_SEG;   // tuning hook
+  static const int seg_cap = std::max(4, dev_knob("CVVDP_R2_SEG", R2_SEG));
   int n_seg = (a.H2 + seg_cap - 1) / seg_cap;
   const int64_t per_seg = (int64_t)bx * a.n_planes * a.n_img;
   n_seg = (int)std::max<int64_t>(n_seg, std::min<int64_t>((4096 + per_seg - 1) / per_seg, (a.H2 + 15) / 16));

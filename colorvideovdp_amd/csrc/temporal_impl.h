@@ -418,7 +418,7 @@ template <int DT, int FL>
 static void launch_fused(const FirArgs& a, hipStream_t s) {
   constexpr int VMAX = FL <= 17 ? 2 : 1;
   const int eb = dtype_bytes(a.dtype);
-  static const int vcap = getenv("CVVDP_FIR_V") ? atoi(getenv("CVVDP_FIR_V")) : 1;   // tuning hook; 1 = scalar pixels + chunked window (fastest)
+  static const int vcap = dev_knob("CVVDP_FIR_V", 1);   // 1 = scalar pixels + chunked window (fastest)
   if constexpr (VMAX == 2 && !is_yuv(DT)) {
     if (vcap >= 2 && a.P % 2 == 0 && can_vectorise(2, a.W, a.sb, a.sc, a.sf, a.sh, a.sw, a.src, eb)) {
       dim3 grid((a.P / 2 + 255) / 256, a.batch, 2);
@@ -428,7 +428,7 @@ static void launch_fused(const FirArgs& a, hipStream_t s) {
   }
   {
     dim3 grid((a.P + 255) / 256, a.batch, 2);
-    static const bool rot = !(getenv("CVVDP_FIR_ROT") && atoi(getenv("CVVDP_FIR_ROT")) == 0);
+    static const bool rot = dev_knob("CVVDP_FIR_ROT", 1) != 0;
     if constexpr (FL <= 17) {
       if (rot) { hipLaunchKernelGGL((k_fir_rot<DT, FL>), grid, dim3(256), 0, s, a); return; }
     }

@@ -731,8 +731,9 @@ class cvvdp(vq_metric):
 
     def distogram_data(self, stats, jod_max=None):
         """The numbers behind a distogram (cvvdp_metric.py:1160-1175): per channel, the JOD loss of every (frame, band)
-        cell, scaled by 1/jod_max.  Returns (panels [channels, bands, frames] in [0,1] with the baseband in the LAST row and
-        band 0 in the first -- the orientation imshow draws --, jod_max)."""
+        cell, scaled by 1/jod_max.  Returns (panels [channels, bands, frames] in [0,1], jod_max).  The band axis is flipped
+        like the reference's np.flip(..., axis=0) (:1192): the baseband (the last band) is row 0, the top row imshow draws,
+        and band 0 (the finest) the bottom row."""
         q = np.array(stats["Q_per_ch"], dtype=f32)
         if q.shape[0] != 1:
             raise vq_exception("Exporting distograms in batch mode is not supported")

@@ -24,10 +24,11 @@ def heatmap_to_uint8(frames):
     if frames.dtype == torch.uint8:
         a = frames.numpy()
         return np.concatenate([a] * 3, -1) if a.shape[-1] == 1 else a
-    a = frames[0].permute(1, 2, 3, 0).float().numpy()            # [n, H, W, C]
+    a = frames[0].permute(1, 2, 3, 0).numpy()                    # [n, H, W, C], float16 like the reference's array
     if a.shape[-1] == 1:
         a = np.concatenate([a] * 3, -1)
-    return (np.clip(a, 0.0, 1.0) * 255.0).astype(np.uint8)
+    assert a.dtype == np.float16
+    return (np.clip(a, 0.0, 1.0) * 255.0).astype(np.uint8)       # float16 product (rounded to half), then truncated: np2vid / np2img
 
 
 class HeatmapPngWriter:

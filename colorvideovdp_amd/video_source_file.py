@@ -80,6 +80,14 @@ def _read_png16(fname):
     return np.ascontiguousarray(((px[..., 0] << 8) | px[..., 1])[..., :3])
 
 
+def _palette_is_grey(im):
+    """A palette image whose every entry has R == G == B is a greyscale image; any other palette carries colour and is
+    decoded to RGB, as the reference's imageio read returns it."""
+    pal = np.asarray(im.getpalette() or [], dtype=np.uint8)
+    pal = pal[:(pal.size // 3) * 3].reshape(-1, 3)
+    return bool(pal.size == 0 or (np.all(pal[:, 0] == pal[:, 1]) and np.all(pal[:, 1] == pal[:, 2])))
+
+
 def load_image_as_array(fname):
     """8- or 16-bit image file -> uint8 / uint16 array [H, W, C] (the reference reads them with imageio, video_source_file.py)."""
     if not os.path.isfile(fname):
@@ -90,7 +98,7 @@ def load_image_as_array(fname):
     with Image.open(fname) as im:
         if im.mode in ("I;16", "I;16B", "I;16L", "I"):
             a = np.asarray(im).astype(np.uint16)[..., None]
-        elif im.mode in ("L", "P", "1"):
+        elif im.mode in ("L", "1") or (im.mode == "P" and _palette_is_grey(im)):
             a = np.asarray(im.convert("L"))[..., None]
         else:
             a = np.asarray(im.convert("RGB"))
@@ -177,6 +185,7 @@ class video_source_image_frames(video_source):
         if self._size is None:
             self._first = self._load_pair(0)
             self._size = (self._first[0].shape[0], self._first[0].shape[1], self.N)
+            self._fmt = (self._first[0].dtype, self._first[0].shape[2])       # every frame of the clip must have these
         return self._size
 
     def get_raw_block(self, first, last, device):
@@ -187,6 +196,9 @@ class video_source_image_frames(video_source):
             pair = self._load_pair(f)
             if pair[0].shape[:2] != (h, w):
                 raise vq_exception(f"Frame {f} ('{self._names(f)[0]}') is {pair[0].shape[1]}x{pair[0].shape[0]}, the first frame {w}x{h}")
+            if (pair[0].dtype, pair[0].shape[2]) != self._fmt:     # (a 16-bit frame assigned into an 8-bit block would wrap silently)
+                raise vq_exception(f"Frame {f} ('{self._names(f)[0]}') is {pair[0].dtype} with {pair[0].shape[2]} channel(s), "
+                                   f"the first frame {self._fmt[0]} with {self._fmt[1]}")
             for side in range(2):
                 a = pair[side]
                 a = a.view(np.int16) if a.dtype == np.uint16 else a        # torch has no uint16 (video_source.py:259-263)

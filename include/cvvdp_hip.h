@@ -10,12 +10,21 @@
  * Conventions
  *   - plain C types only; all `dev` pointers are HIP device pointers (e.g. tensor.data_ptr()).
  *   - every function returns 0 on success, a negative CVVDP_E_* code otherwise; nothing throws.
- *     cvvdp_last_error() returns a human-readable message for the last failure on that handle.
- *   - one handle per (process, GPU); a handle is not thread-safe.
- *   - all device work is enqueued on the caller's hipStream_t (passed as void*); no entry point
- *     synchronises the device.
- *   - the core allocates no device memory: the caller provides one workspace buffer of
- *     cvvdp_workspace_bytes() bytes (so torch's caching allocator stays the only allocator).
+ *     cvvdp_last_error() returns a human-readable message for the last failure of the CALLING THREAD
+ *     (thread-local, so a worker thread's failure cannot garble the main thread's message).
+ *   - one handle per (process, GPU); a handle is not thread-safe, with one exception: cvvdp_unpack_yuv_resized
+ *     touches no handle state and may run on a prefetch thread beside the other calls.
+ *   - all device work is enqueued on the caller's hipStream_t (passed as void*).  Host-side waits happen in
+ *     exactly two places: cvvdp_profile_read (waits for its own timing events) and cvvdp_destroy (drains the
+ *     helper streams the handle owns).  No other entry point synchronises.
+ *   - the core allocates no device MEMORY: the caller provides one workspace buffer of
+ *     cvvdp_workspace_bytes() bytes (so torch's caching allocator stays the only allocator).  It does own a few
+ *     HIP objects, created lazily on first use and destroyed with the handle: two non-blocking helper streams
+ *     with their fork / join events (the small pyramid levels of images and short blocks run beside level 0 on
+ *     them; the caller's stream waits for them by event before anything reads the results) and, while
+ *     profiling is enabled, timing events.
+ *   - the library reads no environment variable (tuning knobs exist only in a -DCVVDP_DEV_KNOBS build,
+ *     cvvdp_build_flags()).
  *   - "item" = one (frame-in-block, batch) pair; item index = frame * batch + b.
  */
 #ifndef CVVDP_HIP_H
@@ -28,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CVVDP_ABI_VERSION 8
+#define CVVDP_ABI_VERSION 9
 #define CVVDP_MAX_FILTER_LEN 65 /* 0.25 s at up to 256 fps, cvvdp_metric.py:1059 */
 #define CVVDP_MAX_LEVELS 16
 #define CVVDP_MAX_WINDOW 256    /* filter_len - 1 + frames per block */
@@ -112,6 +121,11 @@ typedef struct cvvdp_clip {
 typedef struct cvvdp_handle cvvdp_handle;
 
 int cvvdp_abi_version(void);
+/* Bit set of build properties.  CVVDP_BUILD_DEV_KNOBS: compiled with -DCVVDP_DEV_KNOBS, i.e. development tuning
+ * knobs are read from the environment (CVVDP_SEG_TARGET, CVVDP_R2_SEG, ...: they change launch geometry and with it
+ * the last bits of Q_per_ch).  0 for the product build. */
+#define CVVDP_BUILD_DEV_KNOBS 1
+int cvvdp_build_flags(void);
 /* sizeof(cvvdp_params), sizeof(cvvdp_clip) as compiled, so a binding can verify its struct layout. */
 void cvvdp_struct_sizes(int32_t* params_bytes, int32_t* clip_bytes);
 

@@ -264,7 +264,7 @@ def test_fullsize_prefix_against_reference(name):
     g = load_golden(name)
     inp = fullsize_inputs(g)
     if inp is None:
-        pytest.skip("this torch build's CPU generator does not reproduce the fixture's synthetic frames")
+        pytest.fail("this torch build's CPU generator does not reproduce the fixture's synthetic frames (checksum mismatch): the BASELINE-size parity check cannot run -- regenerate tests/golden with oracle/make_goldens_fullsize.py / make_goldens_bench.py")
     jod, stats = cv.cvvdp(display_name=str(g["display"])).predict(inp[0], inp[1], dim_order="BCFHW", frames_per_second=float(g["fps"]))
     assert abs(float(jod) - float(g["jod"])) <= JOD_TOL
     np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
@@ -385,7 +385,7 @@ def test_bench_clip_against_reference(name):
     heat = str(g["heatmap_mode"]) if "heatmap_mode" in g else None
     clip = bench.ResidentClip(F, 0, F, H, W, fps, dtype, torch.device("cuda"), gen="cpu")
     if (clip.checksum_test, clip.checksum_ref) != (int(g["checksum_test"]), int(g["checksum_ref"])):
-        pytest.skip("this torch build's CPU generator does not reproduce the fixture's synthetic frames")
+        pytest.fail("this torch build's CPU generator does not reproduce the fixture's synthetic frames (checksum mismatch): the BASELINE-size parity check cannot run -- regenerate tests/golden with oracle/make_goldens_fullsize.py / make_goldens_bench.py")
     m = cv.cvvdp(display_name=disp, heatmap=heat)
     jod, stats = m.predict_video_source(clip)
     assert m.last_block_frames == min(64, F) or heat is not None       # the geometry the bench runs
@@ -602,6 +602,12 @@ def test_uint8_heatmap_sink_is_the_writers_conversion(tmp_path):
         m = _metric(meta, block_frames=7)
         _, s_full = m.predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
         want = hw.heatmap_to_uint8(s_full["heatmap"])                      # the host conversion of the fp16 tensor: [F, H, W, 3]
+        # ... which must be the reference writers' own expression on the float16 array (run_cvvdp.py:59-63, :76): the product
+        # stays float16 (rounded to half) before the truncation
+        lit = s_full["heatmap"][0].permute(1, 2, 3, 0).numpy()
+        assert lit.dtype == np.float16
+        lit = (np.clip(lit, 0.0, 1.0) * 255.0).astype(np.uint8)
+        np.testing.assert_array_equal(want, np.concatenate([lit] * 3, -1) if lit.shape[-1] == 1 else lit)
         C = 1 if mode == "raw" else 3
         got = np.zeros(want.shape[:3] + (C,), np.uint8)
 

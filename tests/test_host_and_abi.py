@@ -135,3 +135,19 @@ def test_shard_plan_covers_clip():
             for (a, ca), (b, _) in zip(ranges, ranges[1:]):
                 assert a + ca == b
             assert max(c for _, c in ranges) - min(c for _, c in ranges) <= 1
+
+
+def test_heatmap_uint8_conversion_is_the_reference_writers_float16_product():
+    """np2vid / np2img (run_cvvdp.py:59-63, :76) multiply the FLOAT16 heat map by 255.0, which stays float16: the product is
+    rounded to half before it is truncated.  Every fp16 value in [-0.5, 1.5] against that literal expression."""
+    import torch
+    from colorvideovdp_amd import heatmap_writers as hw
+    bits = np.arange(0, 1 << 16, dtype=np.uint16).view(np.float16)
+    v = bits[np.isfinite(bits) & (bits >= -0.5) & (bits <= 1.5)]
+    n = (v.size // 3) * 3
+    frames = torch.from_numpy(v[:n].reshape(1, 3, 1, 1, n // 3).copy())
+    got = hw.heatmap_to_uint8(frames)                                           # [1, 1, n/3, 3]
+    want = (np.clip(frames[0].permute(1, 2, 3, 0).numpy(), 0.0, 1.0) * 255.0).astype(np.uint8)
+    np.testing.assert_array_equal(got, want)
+    f32 = (np.clip(frames[0].permute(1, 2, 3, 0).float().numpy(), 0.0, 1.0) * 255.0).astype(np.uint8)
+    assert (f32 != want).any()                                                  # the fp32 product is NOT the same thing

@@ -4,7 +4,7 @@
 TAG=${1:-ab}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 run() { # name, lib
-  CVVDP_LIB=$2 timeout 600 python bench.py --steps 10 --warmup 3 --cpu-frames 0 > $OUT/$1.json 2> $OUT/$1.err
+  CVVDP_DEV_KNOBS=1 CVVDP_LIB=$2 timeout 600 python bench.py --steps 10 --warmup 3 --cpu-frames 0 > $OUT/$1.json 2> $OUT/$1.err
   python - "$OUT/$1.json" "$1" <<'PY'
 import json,sys
 try:

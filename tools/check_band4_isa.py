@@ -5,8 +5,9 @@ The g-row / coarse-row loads of k_band4 are issued from inline assembly and wait
 `s_waitcnt vmcnt(N)`; the compiler does not know that their destination registers are "in flight" in between.
 This script reads the generated assembly and checks, for every loop of every k_band4 instantiation, that no
 instruction reads or writes a destination register of a stream load between the load and the wait that covers
-it (walking each loop body twice in layout order, so that the back edge is covered; loads return in order, so
-`vmcnt(N)` retires all but the N youngest).
+it (walking each loop body twice in layout order, so that the back edge is covered, and then the whole kernel once in
+layout order for the straight-line code between the loops; loads return in order, so `vmcnt(N)` retires all but the N
+youngest).  `make` runs it on the assembly of the very build it links (csrc/Makefile: band4.isa.ok).
 
     tools/isa_band4.sh && python tools/check_band4_isa.py [/tmp/isa/band4_new.s]
 """
@@ -24,6 +25,37 @@ def regs(tok):
     return out
 
 
+def _walk(name, body, passes, what):
+    """Walk `body` in layout order `passes` times with the queue of vector-memory operations in flight (oldest first);
+    report every instruction that reads or writes the destination of a load that no wait has covered yet."""
+    bad = n_loads = 0
+    queue = []                 # (set of regs, text)
+    for it in range(passes):
+        for l in body:
+            code = l.split(";")[0].strip()
+            if not code or code.endswith(":") or code.startswith("."):
+                continue
+            op = code.split()[0]
+            m = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", code)
+            if m:
+                n = int(m.group(1))
+                while len(queue) > n:
+                    queue.pop(0)
+                continue
+            touched = set(regs(code.split(None, 1)[1])) if len(code.split(None, 1)) > 1 else set()
+            for rs, txt in queue:
+                if touched & rs:
+                    print(f"{name} [{what}]: '{code}' touches v{sorted(touched & rs)} while '{txt}' is in flight")
+                    bad += 1
+            if op.startswith("global_load"):
+                dst = set(regs(code.split(None, 1)[1].split(",")[0]))
+                queue.append((dst, code))
+                n_loads += it == 0
+            elif op.startswith(("global_store", "buffer_store")):
+                queue.append((set(), code))      # stores count in vmcnt on gfx9
+    return bad, n_loads
+
+
 def check_kernel(name, lines):
     # loops = [header label line, last line that branches back to it]
     labels = {l.split(":")[0]: i for i, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:", l)}
@@ -39,30 +71,15 @@ def check_kernel(name, lines):
         # streaming loops = loops that contain a hand-issued load (inline asm shows up between ;;#ASMSTART / ;;#ASMEND)
         if not any("global_load_dwordx4" in l and "ASMSTART" in body[i - 1] for i, l in enumerate(body) if i > 0):
             continue
-        queue = []                 # in-flight loads, oldest first: (set of regs, text)
-        for it in range(2):
-            for l in body:
-                code = l.split(";")[0].strip()
-                if not code or code.endswith(":") or code.startswith("."):
-                    continue
-                op = code.split()[0]
-                m = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", code)
-                if m:
-                    n = int(m.group(1))
-                    while len(queue) > n:
-                        queue.pop(0)
-                    continue
-                touched = set(regs(code.split(None, 1)[1])) if len(code.split(None, 1)) > 1 else set()
-                for rs, txt in queue:
-                    if touched & rs:
-                        print(f"{name}: '{code}' touches v{sorted(touched & rs)} while '{txt}' is in flight")
-                        bad += 1
-                if op.startswith("global_load"):
-                    dst = set(regs(code.split(None, 1)[1].split(",")[0]))
-                    queue.append((dst, code))
-                    n_loads += it == 0
-                elif op.startswith(("global_store", "buffer_store")):
-                    queue.append((set(), code))      # stores count in vmcnt on gfx9
+        b, n = _walk(name, body, 2, f"loop at line {lo}")      # twice around: covers the back edge
+        bad += b
+        n_loads += n
+    # the straight-line code around the loops (prologue -> first loop, loop exit -> drain, epilogue): the whole kernel once in
+    # layout order.  Every loop is followed by a drain (vmcnt(0)) and the taken path of a forward branch is a subsequence of
+    # the layout order, so a register touched on any path between a load and its covering wait is seen here (conservatively:
+    # an untaken arm's accesses count too).
+    b, _ = _walk(name, lines, 1, "layout order")
+    bad += b
     return bad, n_loads, len(loops)
 
 

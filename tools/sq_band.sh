@@ -11,7 +11,7 @@ for lib in "" "$@"; do
              "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_LDS_IDX_ACTIVE" \
              "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD"; do
     i=$((i+1)); rm -rf /tmp/sqb$i
-    ( cd $R && CVVDP_LIB=$lib timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/sqb$i -o sq -- python bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-profile > /tmp/sqb$i.log 2>&1 )
+    ( cd $R && CVVDP_DEV_KNOBS=1 CVVDP_LIB=$lib timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/sqb$i -o sq -- python bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-profile > /tmp/sqb$i.log 2>&1 )
     db=$(find /tmp/sqb$i -name "*.db" | head -1)
     python $R/tools/rocpd_summary.py $db | grep -E "k_band4<4, false, false, false>" | awk '$0 ~ / 6144 /' | awk '{printf "%-26s %18.0f\n", $(NF-3), $NF}'
   done

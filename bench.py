@@ -51,6 +51,45 @@ BUILD_BYTES_PER_PIXEL = {"f32": 24 + 32 + 53.3 + 53.3, "u8": 6 + 32 + 53.3 + 53.
 BAND0_BYTES_PER_PIXEL = 40.0   # level-0 band kernel: reads g0 (8 planes x 4 B) + g1 (8 x 4 / 4)
 
 
+def code_stamp():
+    """What ties profiles/traffic.json (counters from separate rocprofv3 --pmc passes) to the code that is being timed: the
+    SHA-256 of the kernel sources + C header (the build is reproducible from them) and of the built library itself."""
+    import hashlib
+    src = hashlib.sha256()
+    cs = os.path.join(ROOT, "colorvideovdp_amd", "csrc")
+    files = sorted(os.path.join(cs, n) for n in os.listdir(cs) if n.endswith((".hip", ".h", ".cpp")) or n == "Makefile")
+    for p in files + [os.path.join(ROOT, "include", "cvvdp_hip.h")]:
+        src.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            src.update(f.read())
+    lib = os.path.join(ROOT, "colorvideovdp_amd", "libcvvdp_hip.so")
+    lib_sha = None
+    if os.path.isfile(lib):
+        with open(lib, "rb") as f:
+            lib_sha = hashlib.sha256(f.read()).hexdigest()
+    return {"csrc_sha256": src.hexdigest(), "lib_sha256": lib_sha}
+
+
+def host_cpu():
+    """(model string, physical cores, logical cpus) of the box's host processor(s)."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    phys = None
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False)
+    except Exception:
+        pass
+    return model, phys or os.cpu_count() or 1, os.cpu_count() or 1
+
+
 def synth_frame(f, H, W, device, seed_ref=1234, seed_noise=5678):
     """One synthetic test/reference frame pair (uint8 [3,H,W]); depends only on the frame index, so a
     rank can generate exactly its own frame range (SURVEY.md 8(d) recipe: moving plaid + smoothed hash
@@ -74,6 +113,19 @@ def synth_frame(f, H, W, device, seed_ref=1234, seed_noise=5678):
     return torch.round(test.clamp(0, 1) * 255).to(torch.uint8), torch.round(ref * 255).to(torch.uint8)
 
 
+def cpu_frame_pool(frame_ids, H, W):
+    """Iterator over synth_frame(f, H, W, "cpu") for f in frame_ids, made concurrently: ~1 s per 4K frame single-threaded, so
+    several frames at a time (torch releases the GIL), each with a share of the cores (no nested oversubscription).
+    Returns (iterator, pool, torch thread count to restore after pool.shutdown())."""
+    import concurrent.futures
+    ncpu = os.cpu_count() or 1
+    workers = max(1, min(8, ncpu // 4))
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(threads_before, ncpu // workers)))
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers)
+    return pool.map(lambda f: synth_frame(f, H, W, "cpu"), frame_ids), pool, threads_before
+
+
 class ResidentClip:
     """video source whose frames [lo, hi) live in HBM; implements the raw-block fast path.  gen="cpu": the frames are made
     with the CPU generator (the one the reference fixtures were made with) and uploaded; "gpu": made on the device (a
@@ -89,14 +141,8 @@ class ResidentClip:
         self.ref = torch.empty((1, 3, hi - lo, H, W), dtype=tdt, device=device)
         self.checksum_test = self.checksum_ref = 0
         made = None
-        if gen == "cpu":      # ~1 s per 4K frame single-threaded: make several frames concurrently (torch releases the GIL),
-            import concurrent.futures          # each with a share of the cores (no nested oversubscription)
-            ncpu = os.cpu_count() or 1
-            workers = max(1, min(8, ncpu // 4))
-            threads_before = torch.get_num_threads()
-            torch.set_num_threads(max(1, min(threads_before, ncpu // workers)))
-            pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers)
-            made = pool.map(lambda f: synth_frame(f, H, W, "cpu"), range(lo, hi))
+        if gen == "cpu":
+            made, pool, threads_before = cpu_frame_pool(range(lo, hi), H, W)
         for f in range(lo, hi):
             t, r = next(made) if made is not None else synth_frame(f, H, W, device)
             if gen == "cpu":
@@ -168,19 +214,34 @@ class ResidentYuvClip:
         return self.bufs[0][sl], self.bufs[1][sl], self.fmt
 
 
-def cpu_baseline(W, H, fps, display, n_frames):
-    """Oracle ('port' of the reference's torch-CPU path) on the first n_frames of the same synthetic clip."""
+def cpu_baseline(W, H, fps, display, n_frames, frames=None):
+    """SURVEY 8(d) "CPU baseline": the oracle ('port' of the reference's torch-CPU path: same conv2d-based op structure, block = 1
+    frame) on the first n_frames of the same synthetic clip, torch on all PHYSICAL cores of the node; CPU model and core count
+    are reported.  The figure extrapolates linearly in frames (every frame costs the same: the window is a ring)."""
     from oracle import cvvdp_oracle as orc
-    frames = [synth_frame(f, H, W, "cpu") for f in range(n_frames)]
-    t = torch.stack([a for a, _ in frames], dim=1).float().div(255)[None]   # [1,3,F,H,W]
-    r = torch.stack([b for _, b in frames], dim=1).float().div(255)[None]
-    o = orc.Oracle(display)
-    t0 = time.time()
-    with torch.no_grad():
-        jod, _ = o.predict(t, r, dim_order="BCFHW", frames_per_second=fps)
-    dt = time.time() - t0
-    return dict(value=W * H * n_frames / dt / 1e6, unit="Mpixel/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"first {n_frames} frames of the {W}x{H}@{fps} workload clip, oracle/cvvdp_oracle.py (torch CPU, block=1), {dt:.1f} s"), float(jod), t, r
+    model, phys, logical = host_cpu()
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(phys)
+    try:
+        if frames is None:
+            made, pool, tb = cpu_frame_pool(range(n_frames), H, W)
+            frames = list(made)
+            pool.shutdown(wait=True)
+            torch.set_num_threads(phys)
+        t = torch.stack([a for a, _ in frames], dim=1).float().div(255)[None]   # [1,3,F,H,W]
+        r = torch.stack([b for _, b in frames], dim=1).float().div(255)[None]
+        o = orc.Oracle(display)
+        t0 = time.time()
+        with torch.no_grad():
+            jod, _ = o.predict(t, r, dim_order="BCFHW", frames_per_second=fps)
+        dt = time.time() - t0
+    finally:
+        torch.set_num_threads(threads_before)
+    return dict(value=W * H * n_frames / dt / 1e6, unit="Mpixel/s", cores=phys, kind="port", cpu_model=model, logical_cpus=logical,
+                sample=f"first {n_frames} frames of the {W}x{H}@{fps} workload clip (a prefix: the figure extrapolates linearly in frames), "
+                       f"oracle/cvvdp_oracle.py (torch CPU, block=1, {phys} threads = physical cores), {dt:.1f} s",
+                context="the REAL reference in the build container (8 threads, BASELINE.md 2): 0.97 Mpixel/s on 1920x1080 x 24 frames, "
+                        "0.63 Mpixel/s on 3840x2160 x 4 frames"), float(jod), t, r
 
 
 def lockstep_spinup(step, seconds, world, flag_device, sync=lambda: None):
@@ -220,7 +281,7 @@ def main():
     ap.add_argument("--gen", default=None, choices=["cpu", "gpu"], help="frame generator (default: cpu when a reference fixture exists for the clip)")
     ap.add_argument("--frames", type=int, default=None, help="override the workload's frame count (per GPU or total)")
     ap.add_argument("--block-frames", type=int, default=None)
-    ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU baseline sample: a prefix of the workload clip (SURVEY 8d: 16; 0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
 
@@ -350,18 +411,42 @@ def main():
         frames_per_launch = count * args.steps / max(n, 1)
         avg_ms = ms / max(n, 1)
         ach = BAND0_BYTES_PER_PIXEL * W * H * frames_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic, ktraffic = None, None
+        traffic, ktraffic, traffic_note = None, None, "profiles/traffic.json not found"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.isfile(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj.get("workload") == args.workload and tj.get("dtype") == dtype:
+            stamp, have = code_stamp(), tj.get("stamp") or {}
+            if tj.get("workload") != args.workload or tj.get("dtype") != dtype:
+                traffic_note = f"profiles/traffic.json holds counters of workload {tj.get('workload')}/{tj.get('dtype')}, not of this one"
+            elif have.get("csrc_sha256") != stamp["csrc_sha256"]:
+                # counters are collected in separate rocprofv3 --pmc passes (tools/refresh_profiles.sh), not in this run: they are only
+                # quoted when they were measured on exactly these kernel sources
+                traffic_note = ("profiles/traffic.json was measured on other kernel sources (csrc hash "
+                                f"{str(have.get('csrc_sha256'))[:12]} != {stamp['csrc_sha256'][:12]}): counters dropped, refresh them with "
+                                "tools/refresh_profiles.sh + tools/make_traffic_json.py")
+            else:
                 ktraffic = tj.get("kernels")
                 traffic = (ktraffic or {}).get("band_level0", {}).get("hbm_bytes_per_launch")
+                traffic_note = ("FETCH_SIZE x 2 + WRITE_SIZE per launch from separate --pmc passes over these kernel sources (stamp matches; "
+                                f"library binary {'identical' if have.get('lib_sha256') == stamp['lib_sha256'] else 'rebuilt from the same sources'})")
         out["roofline"] = {"bound": "hbm", "kernel": "k_band4<4> level 0 (fused expand/contrast/CSF/masking/blur/pooling)",
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                           "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": n,
+                           "traffic": traffic, "traffic_note": traffic_note, "avg_launch_ms": round(avg_ms, 4), "launches": n,
                            "algorithmic_bytes_per_launch": BAND0_BYTES_PER_PIXEL * W * H * frames_per_launch}
+        # the other two dominant kernels on the same footing (algorithmic bytes per step / HIP-event time per step / 8 TB/s)
+        px_step = W * H * count
+        in_b = {"f32": 24.0, "u8": 6.0, "yuv420p8": 3.0, "yuv420p10": 6.0}[dtype]
+        out["kernel_roofline"] = {}
+        for key, bpp, what in (("temporal_fir", in_b + 32.0, f"{in_b:g} B/pixel in + 32 out (8 level-0 planes)"),
+                               ("pyr_reduce", 32.0 * 4 / 3 + 32.0 / 3, "every level read once (32*4/3 B/pixel), levels 1.. written once (32/3)"),
+                               ("band_level0", BAND0_BYTES_PER_PIXEL, "g0 32 + g1 8 B/pixel in"),
+                               ("band_rest", 40.0 / 3, "levels 1..: (32 + 8)/3 B/pixel in")):
+            kms = prof[key][0] / args.steps
+            if kms > 0:
+                gbs = bpp * px_step / (kms * 1e-3) / 1e9
+                out["kernel_roofline"][key] = {"ms_per_step": round(kms, 3), "algorithmic_bytes_per_pixel": round(bpp, 2), "what": what,
+                                               "achieved_GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4)}
         if ktraffic:
             out["kernel_traffic"] = ktraffic     # counter bytes vs algorithmic bytes of every dominant kernel (profiles/traffic.json)
         tot = sum(v[0] for v in prof.values())

@@ -4,7 +4,9 @@ against algorithmic bytes for every dominant kernel of the 4K x 64 fp32 step.
 
 FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 counts the 128-byte requests of wide coalesced reads as 64 B);
 WRITE_SIZE is used as reported (calibrated on k_fir_rot, whose reads and writes are exactly its algorithmic bytes).
-Usage: make_traffic_json.py r02"""
+The file is stamped with the hash of the kernel sources / library the counters were measured on (profiles/<tag>_stamp.json, written
+by tools/refresh_profiles.sh on the GPU box in the same call); bench.py drops the counters when its own sources differ.
+Usage: make_traffic_json.py r03"""
 import json
 import os
 import sys
@@ -52,7 +54,15 @@ def main(tag):
         kernels[key] = {"kernel": sub, "workgroups": f[0], "FETCH_SIZE_KB_per_launch": f[2], "WRITE_SIZE_KB_per_launch": w[2] if w else None,
                         "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": algo, "measured_over_algorithmic": round(hbm / algo, 4),
                         "algorithmic_bytes": what, "launches_sampled": f[1]}
-    out = {"workload": "4k64", "dtype": "f32", "kernels": kernels,
+    # what the counters were measured on: written next to them ON THE GPU BOX by tools/refresh_profiles.sh (bench.code_stamp():
+    # SHA-256 of the kernel sources + header, and of the library binary).  bench.py quotes the counters only for the same sources.
+    stamp = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_stamp.json")))
+    try:
+        import subprocess
+        stamp["git_head_when_written"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        pass
+    out = {"workload": "4k64", "dtype": "f32", "stamp": stamp, "kernels": kernels,
            "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests of wide coalesced reads as 64 B, MI355X_MICROARCH.md HBM section); "
                          "WRITE_SIZE as reported",
            "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 "
@@ -62,4 +72,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r02")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r03")

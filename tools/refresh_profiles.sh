@@ -4,7 +4,7 @@
 # Writes everything under gpurun_out/refresh/ (merged back by gpurun); copy the *.txt/*.json into profiles/ and run
 # tools/make_traffic_json.py <tag>.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$(pwd)
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
@@ -20,6 +20,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   summ $OUT/pmc_$c > $OUT/${TAG}_pmc_$(echo $c | tr A-Z a-z).txt
 done
 rm -rf $OUT/kt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE     # the rocpd databases are large; keep the summaries
+python -c "import bench, json; print(json.dumps(bench.code_stamp()))" > $OUT/${TAG}_stamp.json     # what these counters were measured on
 # 2b. SQ counters of the three dominant kernels
 tools/sq_counters.sh > $OUT/${TAG}_pmc_sq_counters_body.txt 2> $OUT/sq.err
 # 3. bench lines: the default line (BASELINE metric clip, reference-checked), the other configurations, other input formats
@@ -33,11 +34,17 @@ timeout 900 python bench.py --workload 8k256pq --cpu-frames 0 --steps 2 --warmup
 timeout 900 python bench.py --dtype u8 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --dtype yuv420p8 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --dtype yuv420p10 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
-# 3b. the multi-rank path on this one GPU: 2 ranks over gloo sharing the device (shard plan, halo frames, gather, rank-0 line)
+# 3b. the multi-rank path on this one GPU: 2 ranks over gloo sharing the device (shard plan, halo frames, gather, rank-0 line),
+#     five runs per sharded workload, 120 s limit each: every run must print its JSON line (tests/test_bench_multirank.py)
+: > $OUT/${TAG}_two_ranks_one_gpu_gloo.log
 for w in 4k64 4k1024; do
-  CVVDP_BENCH_BACKEND=gloo CVVDP_BENCH_DEVICE=0 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
-    --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --workload $w --steps 2 --warmup 1 --cpu-frames 0 $([ $w = 4k1024 ] && echo --frames 256) \
-    >> $OUT/${TAG}_two_ranks_one_gpu_gloo.log 2>&1
+  for i in 1 2 3 4 5; do
+    echo "== $w run $i  $(date +%T)" >> $OUT/${TAG}_two_ranks_one_gpu_gloo.log
+    CVVDP_BENCH_BACKEND=gloo CVVDP_BENCH_DEVICE=0 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+      --master-addr 127.0.0.1 --master-port $((29611 + i)) bench.py --gpus 2 --workload $w --steps 2 --warmup 1 --cpu-frames 0 $([ $w = 4k1024 ] && echo --frames 256) \
+      2>&1 | grep -v "amdgpu.ids" >> $OUT/${TAG}_two_ranks_one_gpu_gloo.log
+    echo "== exit ${PIPESTATUS[0]}" >> $OUT/${TAG}_two_ranks_one_gpu_gloo.log
+  done
 done
 # 3c. heat-map path (whole-clip tensor), shard-halo cost, other shapes
 timeout 900 python tools/heatmap_bench.py 4k 32 > $OUT/${TAG}_heatmap_bench.txt 2>&1

@@ -281,6 +281,7 @@ def main():
     ap.add_argument("--gen", default=None, choices=["cpu", "gpu"], help="frame generator (default: cpu when a reference fixture exists for the clip)")
     ap.add_argument("--frames", type=int, default=None, help="override the workload's frame count (per GPU or total)")
     ap.add_argument("--block-frames", type=int, default=None)
+    ap.add_argument("--fps", type=int, default=None, help="override the workload's frame rate (e.g. 120: 31-tap temporal filters, k_fir_fused)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU baseline sample: a prefix of the workload clip (SURVEY 8d: 16; 0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -309,6 +310,7 @@ def main():
     from colorvideovdp_amd.sharding import plan_frame_shard
     W, H, frames, fps, display, per_gpu_frames, wl_dtype, wl_heat = WORKLOADS[args.workload]
     frames = args.frames or frames
+    fps = args.fps or fps
     dtype = args.dtype or wl_dtype
     heat = args.heatmap or wl_heat
     heat = None if heat == "none" else heat
@@ -320,7 +322,7 @@ def main():
     fl = int(np.ceil(0.250 * fps / 2) * 2) + 1   # cvvdp_metric.py:1059
     lo = max(0, first - (fl - 1))
     golden = None
-    if world == 1 and args.frames is None and (args.workload, dtype) in GOLDEN:
+    if world == 1 and args.frames is None and args.fps is None and (args.workload, dtype) in GOLDEN:
         gpath = os.path.join(ROOT, "tests", "golden", GOLDEN[(args.workload, dtype)] + ".npz")
         if os.path.isfile(gpath):
             golden = np.load(gpath, allow_pickle=False)
@@ -374,7 +376,7 @@ def main():
     what = f"{W}x{H} {fps}fps, {display}, {dtype} input resident in HBM"
     if world > 1:
         what += (f", {frames}-frame clip pair per GPU ({n_total} frames total)" if per_gpu_frames else f", {n_total}-frame clip pair over {world} GPUs") \
-                + ", frame-range shards + 16-frame halo, one all-gather of Q_per_ch"
+                + f", frame-range shards + {fl - 1}-frame halo, one all-gather of Q_per_ch"
     else:
         what += f", {n_total}-frame clip pair"
     if heat is not None:

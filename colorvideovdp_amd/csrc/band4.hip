@@ -27,7 +27,8 @@
 //
 // Image-edge halo columns are produced by the in-image lanes as mirrored LDS writes (reflect padding
 // of the blur), halo rows by evaluating the reflected row.  Instantiations: NCH (3 image / 4 video channels), HEAT
-// (per-pixel heat-map band), RAGGED (W % 8 != 0: partial last lane, shifted coarse chunks), DUMP (per-pixel D).
+// (per-pixel heat-map band), RAGGED (W % 8 != 0: partial last lane, shifted coarse chunks), DUMP (per-pixel D), FEAT (the
+// statistics of the ML heads' feature pooling, accumulated in the row march: see FEATURES below).
 #include <type_traits>
 #include "kernels.h"
 
@@ -58,8 +59,8 @@ __device__ __forceinline__ int refl(int i, int n) {
   return i;
 }
 
-template <int NCH, bool HEAT, bool RAGGED, bool DUMP>
-__global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
+template <int NCH, bool HEAT, bool RAGGED, bool DUMP, bool FEAT>
+__global__ __launch_bounds__(64 * NCH, FEAT ? 2 : 3) void k_band4(BandArgs a) {
   constexpr int NP = 2 * NCH;
   // s_ve is a ring of two rows (row parity): row r+1 is written during phase 1 of row r, so that phase 2 can derive
   // the per-column luminance terms of row r+1 (s_lum) from its luminance planes (0, 1).
@@ -85,8 +86,8 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   // overlapping halo columns and shared 128-byte lines are then fetched from HBM once instead of once per strip.
   const int per_xcd = a.per_xcd;
   const int wu = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-  if (wu >= a.n_strip * a.n_seg * a.items) return;      // (block-uniform: the grid is rounded up to 8 * per_xcd)
-  const int strip = wu % a.n_strip, seg = (wu / a.n_strip) % a.n_seg, item = wu / (a.n_strip * a.n_seg);
+  if (wu >= a.n_strip_l * a.n_seg * a.items) return;    // (block-uniform: the grid is rounded up to 8 * per_xcd)
+  const int strip = a.strip0 + wu % a.n_strip_l, seg = (wu / a.n_strip_l) % a.n_seg, item = wu / (a.n_strip_l * a.n_seg);
   const int H = a.H, W = a.W, Hc = a.Hc, Wc = a.Wc;
   const int x0 = strip * B4_SW;
   const int fc0 = x0 - B4_HALO + 4 * j;             // first of this lane's 4 columns
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   float inv_dmax = a.inv_dmax;
   if constexpr (!RAGGED) {   // (the ragged instantiation is short of VGPRs instead)
     B4_IN_VGPR(ind_k0); B4_IN_VGPR(xw1); B4_IN_VGPR(xw2); B4_IN_VGPR(xw3); B4_IN_VGPR(m1c); B4_IN_VGPR(inv_dmax);
-    if constexpr (!HEAT && !DUMP) {   // (those instantiations have no VGPRs to spare)
+    if constexpr ((!HEAT && !DUMP) || FEAT) {   // (those instantiations have no VGPRs to spare; FEAT runs two blocks per CU: 256)
       B4_IN_VGPR(e0); B4_IN_VGPR(e1); B4_IN_VGPR(eo); B4_IN_VGPR(mask_p); B4_IN_VGPR(eps_p);
       B4_IN_VGPR(qc); B4_IN_VGPR(ind_k1); B4_IN_VGPR(xw0);
     }
@@ -276,6 +277,32 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   for (int k = 0; k < B4_BW; ++k) wr[k] = a.blur[(k + B4_BW - 1) % B4_BW];
   float acc = 0.0f;
 
+  // ---- FEATURES (cvvdp_feature_pooling, cvvdp_ml_metric.py:77-107, called at :351-358): mean and E[x^2] of
+  // |T'| = |T_f|*S, |R'| and D over feature_size x feature_size cells.  The march accumulates, per lane and COLUMN, the sums of
+  // the six quantities over the rows of the current cell row (24 registers; this instantiation runs two blocks per CU) and
+  // stores them as one row of column sums when the march crosses a cell-row boundary or leaves the segment: 24 B per pixel
+  // and boundary -- 24/fs B/pixel of traffic instead of the 96 B/pixel of per-pixel planes.  A piece of a cell row is keyed
+  // (cell row + segment index), which is unique (segments ascend with the rows); k_feature_finish adds the pieces and the
+  // columns of each cell in double, in a fixed order.  Rows: |T'|, |R'| belong to row r of the contrast stage, D to the row
+  // of the pooling stage (seven rows behind): two independent trackers.
+  float f_t[4] = {0, 0, 0, 0}, f_t2[4] = {0, 0, 0, 0}, f_r[4] = {0, 0, 0, 0}, f_r2[4] = {0, 0, 0, 0}, f_d[4] = {0, 0, 0, 0}, f_d2[4] = {0, 0, 0, 0};
+  int f_left_tr = 0, f_left_d = 0;                  // rows to the next cell-row boundary (scalar)
+  if constexpr (FEAT) { f_left_tr = f_left_d = a.fs - ys % a.fs; }
+  auto feat_store = [&](int y_last, int q0, const float (&s0)[4], const float (&s1)[4]) {   // column sums of the piece that ends with row y_last
+    if constexpr (FEAT) {
+      if (interior) {
+        const int piece = y_last / a.fs + seg;
+        float* dst = a.fsum + ((((int64_t)item * NCH + c) * a.f_pieces + piece) * 6 + q0) * W + fc0;
+        if (n_valid == 4) {
+          *reinterpret_cast<f4u*>(dst) = f4u{s0[0], s0[1], s0[2], s0[3]};
+          *reinterpret_cast<f4u*>(dst + W) = f4u{s1[0], s1[1], s1[2], s1[3]};
+        } else {
+          for (int i = 0; i < n_valid; ++i) { dst[i] = s0[i]; dst[W + i] = s1[i]; }
+        }
+      }
+    }
+  };
+
   // pooling stage of centre row y (cvvdp_metric.py:849-856, 722): needs s_q of all channels and s_d (ring slot k7)
   auto stage3c = [&](int y, int k7) {
     const f4 q0 = lds_read4(&s_q[0][4 * j]), q1 = lds_read4(&s_q[1][4 * j]), q2 = lds_read4(&s_q[2][4 * j]);
@@ -300,6 +327,10 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc += D[i] * (D[i] + 2.0f * kEps);   // (D+eps)^2 - eps^2
+    if constexpr (FEAT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f_d[i] += D[i]; f_d2[i] = __builtin_fmaf(D[i], D[i], f_d2[i]); }
+    }
     if constexpr (DUMP) {                                           // per-pixel D for tests / features (its own instantiation)
       float* dd = a.ddump + (int64_t)c * a.items_cap * P + (int64_t)item * P + (int64_t)y * W + fc0;
       if (n_valid == 4) *reinterpret_cast<f4u*>(dd) = f4u{D[0], D[1], D[2], D[3]};
@@ -413,6 +444,15 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
     // ================= phase 1
     const int yprev = r - 1 - B4_R;                  // row whose Mq was published last iteration (ring slot k7, like row r)
     if (interior && yprev >= ys) stage3c(yprev, k7);
+    if constexpr (FEAT) {                             // D sums: a cell row ends with row yprev (the segment's last row is the epilogue's)
+      if (yprev >= ys && --f_left_d == 0) {
+        feat_store(yprev, 4, f_d, f_d2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f_d[i] = f_d2[i] = 0.0f;
+        f_left_d = a.fs;
+      }
+    }
+    const bool feat_row = FEAT && r >= ys && r < ye;  // (scalar) row r belongs to this segment: its |T'|, |R'| are counted
     if (in_img) {
       float exT[4], exR[4];
       expand4(s_ve[ODD][2 * c], exT);
@@ -436,7 +476,13 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
         const float S = Sv.v[i];
         const float ct = fminf((gt[i] - exT[i]) * rLt.v[i], 1000.0f);            // lpyr_dec.py:402 (band gain :66 is in S)
         const float cr = fminf((gr[i] - exR[i]) * rLr.v[i], 1000.0f);
-        m[i] = fminf(fabsf(ct), fabsf(cr)) * S;                                  // min(|T'|,|R'|), T' = ct*S (cvvdp_metric.py:845)
+        if constexpr (FEAT) {
+          const float at = fabsf(ct) * S, ar = fabsf(cr) * S;                    // |T'|, |R'| (the channel gain inside S is divided out by k_feature_finish)
+          m[i] = fminf(at, ar);                                                  // = min(|ct|,|cr|)*S bit for bit (rounding is monotone)
+          if (feat_row) { f_t[i] += at; f_t2[i] = __builtin_fmaf(at, at, f_t2[i]); f_r[i] += ar; f_r2[i] = __builtin_fmaf(ar, ar, f_r2[i]); }
+        } else {
+          m[i] = fminf(fabsf(ct), fabsf(cr)) * S;                                // min(|T'|,|R'|), T' = ct*S (cvvdp_metric.py:845)
+        }
         d[i] = fabsf(ct - cr) * S + kEps;                                        // |T'-R'| + eps (:855, safe_pow)
       }
       lds_write4(&s_m[c][4 * j], m);
@@ -458,6 +504,15 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
             if (x >= W - 1 - B4_R && x <= W - 2 && idx < 256) s_m[c][idx] = m[i];
           }
         }
+      }
+    }
+    if constexpr (FEAT) {
+      if (feat_row && (--f_left_tr == 0 || r == ye - 1)) {
+        feat_store(r, 0, f_t, f_t2);
+        feat_store(r, 2, f_r, f_r2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f_t[i] = f_t2[i] = f_r[i] = f_r2[i] = 0.0f;
+        f_left_tr = a.fs;
       }
     }
     coarse_finish(ODD ? 0 : 1, std::integral_constant<bool, !ODD>{}, fin_fast);   // vertical expand of row r+1 (its coarse row was requested a phase ago)
@@ -540,6 +595,9 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
   }
   // ---- epilogue: pooling stage of the last centre row
   if (interior && (ye - 1) >= ys) stage3c(ye - 1, k7);    // row ye-1 = rend-7 shares the ring slot of row rend
+  if constexpr (FEAT) {
+    if ((ye - 1) >= ys) feat_store(ye - 1, 4, f_d, f_d2);
+  }
   if constexpr (HEAT) {
     __syncthreads();
     if ((ye - 1) >= ys) heat_row(ye - 1);
@@ -562,28 +620,52 @@ __global__ __launch_bounds__(64 * NCH, 3) void k_band4(BandArgs a) {
 template <bool RAGGED>
 static void launch_band4_w(const BandArgs& a, hipStream_t s) {
   dim3 grid(8 * a.per_xcd);
-  if (a.dchr) {          // heat map (with or without the per-pixel dump)
+  if (a.fsum) {          // features for the ML heads (no heat map, no dump: extract_features refuses the one, core.cpp never sets the other)
+    if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, false, RAGGED, false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_band4<3, false, RAGGED, false, true>), grid, dim3(192), 0, s, a);
+  } else if (a.dchr) {   // heat map (with or without the per-pixel dump)
     if (a.ddump) {
-      if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, true, RAGGED, true>), grid, dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((k_band4<3, true, RAGGED, true>), grid, dim3(192), 0, s, a);
+      if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, true, RAGGED, true, false>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k_band4<3, true, RAGGED, true, false>), grid, dim3(192), 0, s, a);
     } else {
-      if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, true, RAGGED, false>), grid, dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((k_band4<3, true, RAGGED, false>), grid, dim3(192), 0, s, a);
+      if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, true, RAGGED, false, false>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k_band4<3, true, RAGGED, false, false>), grid, dim3(192), 0, s, a);
     }
   } else if (a.ddump) {
-    if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, false, RAGGED, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_band4<3, false, RAGGED, true>), grid, dim3(192), 0, s, a);
+    if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, false, RAGGED, true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_band4<3, false, RAGGED, true, false>), grid, dim3(192), 0, s, a);
   } else {
-    if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, false, RAGGED, false>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_band4<3, false, RAGGED, false>), grid, dim3(192), 0, s, a);
+    if (a.nch == 4) hipLaunchKernelGGL((k_band4<4, false, RAGGED, false, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_band4<3, false, RAGGED, false, false>), grid, dim3(192), 0, s, a);
   }
 }
 
-void launch_band4(const BandArgs& a0, hipStream_t s) {
+// W % 8 != 0: a lane of the last strip, or a coarse 4-column chunk, straddles the right image edge.  Only the strips that
+// can see that edge need the RAGGED instantiation (partial lane, shifted coarse chunks, per-column mirrors: 5 spilled VGPRs and
+// ~75 spilled SGPRs in the row loop): a strip whose 256 columns x0-8 .. x0+247 end inside the image (x0 + 248 <= W, which also
+// keeps its coarse chunks inside: 2*Wc >= W) runs exactly the instructions of an aligned image -- rows of any pitch are fine,
+// the 16-byte loads only need 4-byte alignment.
+int band4_edge_strips(int W, int n_strip) {
+  if ((W & 7) == 0) return 0;
+  int n = 0;
+  while (n < n_strip && (n_strip - 1 - n) * B4_SW + B4_SW + B4_HALO > W) ++n;
+  return n;
+}
+
+void launch_band4(const BandArgs& a0, bool split_edge, hipStream_t s, hipStream_t s_edge) {
   BandArgs a = a0;
-  a.per_xcd = (a.n_strip * a.n_seg * a.items + 7) / 8;
-  if (a.W & 7) launch_band4_w<true>(a, s);       // a lane of the last strip, or a coarse 4-column chunk, straddles the right image edge
-  else launch_band4_w<false>(a, s);
+  int n_edge = band4_edge_strips(a.W, a.n_strip);
+  if (n_edge > 0 && !split_edge) n_edge = a.n_strip;  // one launch: every strip on the RAGGED instantiation
+  if (n_edge > 0) {                                  // the few edge strips first: on their own stream they run beside the rest
+    a.strip0 = a.n_strip - n_edge; a.n_strip_l = n_edge;
+    a.per_xcd = (a.n_strip_l * a.n_seg * a.items + 7) / 8;
+    launch_band4_w<true>(a, s_edge);
+  }
+  if (n_edge < a.n_strip) {
+    a.strip0 = 0; a.n_strip_l = a.n_strip - n_edge;
+    a.per_xcd = (a.n_strip_l * a.n_seg * a.items + 7) / 8;
+    launch_band4_w<false>(a, s);
+  }
 }
 
 }  // namespace cvvdp

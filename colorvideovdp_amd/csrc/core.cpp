@@ -18,7 +18,10 @@ namespace {
 struct Level {
   int H = 0, W = 0;
   int64_t P = 0;
-  size_t g_off = 0, heat_off = 0, dd_off = 0, fd_off = 0;  // float offsets into the workspace
+  size_t g_off = 0, heat_off = 0, dd_off = 0, fd_off = 0, fs_off = 0;  // float offsets into the workspace
+  bool split_edge = false;   // k_band4, W % 8 != 0: aligned strips and edge strips as two launches (decided per clip, not per block)
+  bool feat4 = false;   // features mode and the level runs on k_band4: column sums (fs_off) instead of per-pixel planes (dd_off, fd_off)
+  int f_pieces = 0;
   size_t partial_off = 0;   // this level's partial sums (levels run concurrently: no sharing)
   int n_strip = 1, n_seg = 1, seg_h = 1;
   bool blur = false;
@@ -53,6 +56,10 @@ struct cvvdp_handle {
   // the small pyramid levels (2 and up: each less than a GPU-full of workgroups) run beside level 0 / 1 on two side streams
   hipStream_t aux_stream[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  // frames whose width is not a multiple of 8: the one or two strips at the right image edge (RAGGED instantiation of k_band4) run
+  // on their own stream beside the aligned strips of the same level
+  hipStream_t edge_stream = nullptr;
+  hipEvent_t ev_edge_fork = nullptr, ev_edge_join = nullptr;
   hipEvent_t ev_reduce[2] = {nullptr, nullptr}, ev_band[2] = {nullptr, nullptr};
   bool band_pending[2] = {false, false};
 };
@@ -236,10 +243,33 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
     a.dchr = heat ? h->ws + lv.heat_off : nullptr;
     heat_weights(h, false, a.hw);
     a.beta_tch = h->p.beta_tch; a.eps_btch = std::pow(kEps, h->p.beta_tch); a.eps_inv_btch = std::pow(kEps, 1.0f / h->p.beta_tch);
-    a.ddump = (h->c.debug_dump || h->c.feature_size > 0) ? h->ws + lv.dd_off : nullptr;
-    a.fdump = h->c.feature_size > 0 ? h->ws + lv.fd_off : nullptr;
-    if (lv.vec4) launch_band4(a, s);
-    else launch_band(a, lv.blur, s);
+    a.ddump = (h->c.debug_dump || (h->c.feature_size > 0 && !lv.feat4)) ? h->ws + lv.dd_off : nullptr;
+    a.fdump = (h->c.feature_size > 0 && !lv.feat4) ? h->ws + lv.fd_off : nullptr;
+    a.fsum = lv.feat4 ? h->ws + lv.fs_off : nullptr; a.fs = h->c.feature_size; a.f_pieces = lv.f_pieces;
+    if (lv.vec4) {
+      // W % 8 != 0: the edge strips are a small launch (n_seg * items workgroups) of a slower instantiation; in the same stream it
+      // would cost a whole extra round of the row march, on its own stream it fills the GPU together with the aligned strips.
+      // (Not while profiling: the per-kernel events sit on one stream.)
+      hipStream_t s_edge = s;
+      if (lv.split_edge && !h->prof) {
+        if (!h->edge_stream) {
+          if (hipStreamCreateWithFlags(&h->edge_stream, hipStreamNonBlocking) != hipSuccess ||
+              hipEventCreateWithFlags(&h->ev_edge_fork, hipEventDisableTiming) != hipSuccess ||
+              hipEventCreateWithFlags(&h->ev_edge_join, hipEventDisableTiming) != hipSuccess)
+            return fail(h, CVVDP_E_HIP, "cannot create the edge-strip stream of the band stage");
+        }
+        s_edge = h->edge_stream;
+        (void)hipEventRecord(h->ev_edge_fork, s);                   // after the pyramid (and whatever else precedes this level on s)
+        (void)hipStreamWaitEvent(s_edge, h->ev_edge_fork, 0);
+      }
+      launch_band4(a, lv.split_edge, s, s_edge);
+      if (s_edge != s) {                                            // the finish kernel below reads the partial sums of both launches
+        (void)hipEventRecord(h->ev_edge_join, s_edge);
+        (void)hipStreamWaitEvent(s, h->ev_edge_join, 0);
+      }
+    } else {
+      launch_band(a, lv.blur, s);
+    }
     FinalizeArgs f{};
     f.partial = a.partial; f.items = items; f.nblk = lv.n_strip * lv.n_seg; f.nch = nch; f.P = (int)lv.P;
     f.q_out = h->ws + h->q_off; f.q_frames = h->c.n_frames; f.q_levels = L; f.q_frame_offset = q_frame_offset;
@@ -321,6 +351,9 @@ void cvvdp_destroy(cvvdp_handle* h) {
     if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
   }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->edge_stream) { (void)hipStreamSynchronize(h->edge_stream); (void)hipStreamDestroy(h->edge_stream); }
+  if (h->ev_edge_fork) (void)hipEventDestroy(h->ev_edge_fork);
+  if (h->ev_edge_join) (void)hipEventDestroy(h->ev_edge_join);
   delete h;
 }
 
@@ -360,7 +393,8 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     Level& lv = h->lv[l];
     lv.H = H; lv.W = W; lv.P = (int64_t)H * W;
     lv.blur = pad > 0 && H > pad && W > pad;
-    lv.vec4 = lv.blur && W >= 16 && H >= 16 && c.feature_size <= 0;   // (features mode: the generic kernel writes |T'|, |R'|)
+    lv.vec4 = lv.blur && W >= 16 && H >= 16;
+    lv.feat4 = c.feature_size > 0 && lv.vec4 && l + 1 < h->L;          // (the baseband and the tiny levels keep per-pixel |T'|, |R'|, D planes)
     const int sw = lv.vec4 ? kBand4StripWidth : (lv.blur ? 256 - 2 * pad : 256);
     lv.n_strip = (W + sw - 1) / sw;
     // Row segments.  Every segment recomputes 12 blur-halo rows, so segments should be long; a block marches ~2.6 us
@@ -383,6 +417,13 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
       lv.seg_h = (H + lv.n_seg - 1) / lv.n_seg;
       lv.seg_h += lv.seg_h & 1;               // even: k_band4 unrolls its row loop over even/odd row pairs
       lv.n_seg = (H + lv.seg_h - 1) / lv.seg_h;
+      // W % 8 != 0: only the one or two strips at the right image edge need the RAGGED instantiation of k_band4 (spills in its row
+      // loop).  Splitting them off pays when the aligned rest is at least two GPU-fulls of workgroups on its own; a launch of
+      // one round takes one block's march however it is split (measured: 1366x768 x 64, 768 workgroups, 3.23 -> 3.71 ms with
+      // the split -- two launches and two event hops per level for nothing).  Decided from the nominal block, like the
+      // segments: the same kernels score a frame whatever the block size, so results stay bit-identical.
+      const int n_edge = lv.vec4 ? band4_edge_strips(W, lv.n_strip) : 0;
+      lv.split_edge = n_edge > 0 && n_edge < lv.n_strip && (int64_t)(lv.n_strip - n_edge) * lv.n_seg * nominal * c.batch >= 1536;
     }
     if (l + 1 < h->L && (H < 2 || W < 2)) return fail(h, CVVDP_E_ARG, "pyramid too deep for %dx%d", c.width, c.height);
     H = (H + 1) / 2; W = (W + 1) / 2;
@@ -416,8 +457,14 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     h->hstats_off = off; off += align_up((size_t)h->items_cap * kHeatStatsWords);
     h->hcurve_off = off; off += align_up((size_t)h->items_cap * kHeatCurveWords);
   }
-  if (c.debug_dump || c.feature_size > 0) for (auto& lv : h->lv) { lv.dd_off = off; off += align_up((size_t)4 * h->items_cap * lv.P); }
-  if (c.feature_size > 0) for (auto& lv : h->lv) { lv.fd_off = off; off += align_up((size_t)8 * h->items_cap * lv.P); }
+  for (auto& lv : h->lv) {
+    if (c.debug_dump || (c.feature_size > 0 && !lv.feat4)) { lv.dd_off = off; off += align_up((size_t)4 * h->items_cap * lv.P); }
+    if (c.feature_size > 0 && !lv.feat4) { lv.fd_off = off; off += align_up((size_t)8 * h->items_cap * lv.P); }
+    if (lv.feat4) {   // column sums per piece of a cell row (band4.hip, FEATURES)
+      lv.f_pieces = (lv.H + c.feature_size - 1) / c.feature_size + lv.n_seg;
+      lv.fs_off = off; off += align_up((size_t)h->items_cap * h->nch * lv.f_pieces * 6 * lv.W);
+    }
+  }
   h->ws_floats = off;
   h->ws = nullptr;
   h->configured = true;
@@ -681,6 +728,16 @@ int cvvdp_get_features(cvvdp_handle* h, int32_t band, int32_t n_frames, float* d
   if (band < 0 || band >= h->L) return fail(h, CVVDP_E_ARG, "bad band");
   if (!dev_out || n_frames < 1 || n_frames * h->c.batch != h->last_items) return fail(h, CVVDP_E_ARG, "n_frames does not match the last block");
   const Level& lv = h->lv[band];
+  if (lv.feat4) {
+    FeatFinishArgs f{};
+    f.fsum = h->ws + lv.fs_off;
+    f.H = lv.H; f.W = lv.W; f.items = h->last_items; f.nch = h->nch; f.fs = h->c.feature_size;
+    f.Hc = (lv.H + f.fs - 1) / f.fs; f.Wc = (lv.W + f.fs - 1) / f.fs; f.f_pieces = lv.f_pieces; f.seg_h = lv.seg_h;
+    for (int c = 0; c < 4; ++c) f.inv_gain[c] = 1.0f / h->p.ch_gain[c];
+    f.out = dev_out;
+    launch_feature_finish(f, static_cast<hipStream_t>(stream));
+    return check_launch(h, "feature finish");
+  }
   FeatPoolArgs a{};
   a.tr = h->ws + lv.fd_off; a.d = h->ws + lv.dd_off;
   a.H = lv.H; a.W = lv.W; a.items = h->last_items; a.items_cap = h->items_cap; a.nch = h->nch; a.fs = h->c.feature_size;

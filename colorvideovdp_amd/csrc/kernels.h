@@ -146,6 +146,7 @@ struct BandArgs {
   int32_t items, items_cap, nch;
   int32_t seg_h, n_seg, n_strip;
   int32_t per_xcd;   // k_band4: work units per XCD (set by launch_band4)
+  int32_t strip0, n_strip_l;   // k_band4: this launch covers strips strip0 .. strip0 + n_strip_l - 1 (set by launch_band4)
   float band_mul;
   float lut[4 * CVVDP_CSF_NODES];
   float logL_first, logL_last;
@@ -167,9 +168,18 @@ struct BandArgs {
   float beta_tch, eps_btch, eps_inv_btch;
   float* ddump;      // debug [4][items_cap][H*W] or null
   float* fdump;      // features: |T'|, |R'| as [2][4][items_cap][H*W] or null (k_band only)
+  // k_band4 in features mode: column sums of |T'|, |T'|^2, |R'|, |R'|^2, D, D^2 per piece of a cell row,
+  // [items][nch][f_pieces][6][W] (piece = cell row + segment index; f_pieces = ceil(H / fs) + n_seg), or null
+  float* fsum;
+  int32_t fs, f_pieces;
 };
 void launch_band(const BandArgs& a, bool blur, hipStream_t s);
-void launch_band4(const BandArgs& a, hipStream_t s);   // vectorised variant: W % 8 == 0, blur on, seg_h even
+// vectorised variant: any W >= 16, blur on, seg_h even.  W % 8 != 0: every strip on the RAGGED instantiation, or (split_edge) the
+// strips that stay clear of the right image edge on the aligned instantiation on s and the one or two edge strips on the RAGGED
+// one on s_edge (a side stream the caller has made wait for the pyramid and will join before reading the partial sums;
+// s_edge == s: one after the other)
+void launch_band4(const BandArgs& a, bool split_edge, hipStream_t s, hipStream_t s_edge);
+int band4_edge_strips(int W, int n_strip);   // how many trailing strips the RAGGED instantiation takes (0 when W % 8 == 0)
 constexpr int kBand4StripWidth = 240;
 
 struct BaseArgs {
@@ -192,6 +202,13 @@ struct FinalizeArgs {
 };
 void launch_finalize(const FinalizeArgs& a, hipStream_t s);
 
+struct FeatFinishArgs {      // cvvdp_feature_pooling from the column sums k_band4 keeps in features mode
+  const float* fsum;         // [items][nch][f_pieces][6][W]
+  int32_t H, W, items, nch, fs, Hc, Wc, f_pieces, seg_h;
+  float inv_gain[4];
+  float* out;                // [items][Hc][Wc][nch][6]
+};
+void launch_feature_finish(const FeatFinishArgs& a, hipStream_t s);
 struct FeatPoolArgs {        // cvvdp_feature_pooling, cvvdp_ml_metric.py:77-107
   const float* tr;           // |T'|, |R'|: [2][4][items_cap][P]
   const float* d;            // D: [4][items_cap][P]

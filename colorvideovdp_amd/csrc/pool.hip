@@ -91,6 +91,48 @@ __global__ __launch_bounds__(256) void k_feature_pool(FeatPoolArgs a) {
   }
 }
 
+// The same statistics from the column sums k_band4 keeps in features mode (band4.hip, FEATURES): one wave per (cell, item,
+// channel); lane <-> column of the cell, pieces of the cell row (one per row segment that overlaps it) added in ascending
+// order, then the columns across the wave -- all in double, in a fixed order (deterministic).
+__global__ __launch_bounds__(64) void k_feature_finish(FeatFinishArgs a) {
+  const int cx = blockIdx.x, cy = blockIdx.y;
+  const int item = blockIdx.z / a.nch, c = blockIdx.z - item * a.nch;
+  const int x0 = cx * a.fs, y0 = cy * a.fs;
+  const int w = min(a.fs, a.W - x0), h = min(a.fs, a.H - y0);
+  const int seg_lo = y0 / a.seg_h, seg_hi = (y0 + h - 1) / a.seg_h;
+  const float* base = a.fsum + ((int64_t)item * a.nch + c) * a.f_pieces * 6 * a.W;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int xx = threadIdx.x; xx < w; xx += 64) {
+    for (int sg = seg_lo; sg <= seg_hi; ++sg) {
+      const float* p = base + (int64_t)(cy + sg) * 6 * a.W + x0 + xx;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] += (double)p[(int64_t)k * a.W];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_down(acc[k], off, 64);
+  }
+  if (threadIdx.x == 0) {
+    const double n = (double)w * h, ig = (double)a.inv_gain[c];
+    const double scale[6] = {ig, ig * ig, ig, ig * ig, 1.0, 1.0};     // |T'|, |R'| carry the channel gain, the reference's features do not
+    float* out = a.out + ((((int64_t)item * a.Hc + cy) * a.Wc + cx) * a.nch + c) * 6;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float mean = (float)(acc[2 * q] * scale[2 * q] / n);
+      const float msq = (float)(acc[2 * q + 1] * scale[2 * q + 1] / n);
+      out[2 * q] = mean;
+      out[2 * q + 1] = msq - mean * mean;         // fp32, like the reference's avg_pool(x**2) - mean**2
+    }
+  }
+}
+
+void launch_feature_finish(const FeatFinishArgs& a, hipStream_t s) {
+  dim3 grid(a.Wc, a.Hc, a.items * a.nch);
+  hipLaunchKernelGGL(k_feature_finish, grid, dim3(64), 0, s, a);
+}
+
 void launch_feature_pool(const FeatPoolArgs& a, hipStream_t s) {
   dim3 grid(a.Wc, a.Hc, a.items * a.nch);
   hipLaunchKernelGGL(k_feature_pool, grid, dim3(256), 0, s, a);

@@ -244,6 +244,11 @@ __global__ __launch_bounds__(256) void k_reduce_vec(ReduceArgs a) {
 constexpr int R2_LANES = 62;   // lanes of a wave that own level-(l+2) columns
 constexpr int R2_SEG = 64;     // most level-(l+2) rows per thread (launch_reduce2 balances the segments)
 
+// ANYW = false: W_l % 16 == 0 (aligned accesses, the last columns of both levels in fixed slots).  ANYW = true: any width >= 32:
+// level l goes through hreduce_row_any (per-sample borders), level-(l+1) columns outside the image are the zero padding of the
+// second pass, the last level-(l+2) column W2-1 can be either of the lane's two and takes its edge samples W1-1, W1-2 from the
+// lane's own quad or its left neighbour's last column, stores are unaligned / partial at the right border.
+template <bool ANYW>
 __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
   const int img = blockIdx.z;
   const int plane = img / a.n_img, it = img - plane * a.n_img;
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
   float* out2 = a.out2 + ib * a.H2 * a.W2;
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   const int v = wave * R2_LANES + lane - 1;                 // quad index: level-(l+1) columns 4v .. 4v+3
-  const int nq = a.W1 >> 2;
+  const int nq = ANYW ? (a.W1 + 3) >> 2 : a.W1 >> 2;
   if (wave * R2_LANES >= nq) return;                        // whole wave right of the image (wave-uniform)
   const int c1 = 4 * v;
   const bool in1 = v >= 0 && v < nq;
@@ -272,9 +277,17 @@ __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
   const int wave0 = (blockIdx.x * 256) >> 6;
   const bool edge = wave0 == 0 || (wave0 + 4) * R2_LANES + 1 >= nq;
   const float live = in1 ? 1.0f : 0.0f;
+  // ANYW: validity of the lane's four level-(l+1) columns, and where the last level-(l+2) column and its edge samples sit
+  const int nv1 = ANYW ? min(max(a.W1 - c1, 0), 4) * (v >= 0 ? 1 : 0) : 4;       // columns c1 .. c1+nv1-1 exist
+  const int slot2 = ANYW ? (a.W2 - 1) - 2 * v : 1;                               // 0 / 1: this lane owns column W2-1 in that slot
+  const int e1i = a.W1 - 1 - c1, e2i = a.W1 - 2 - c1;                            // quad index of samples W1-1, W1-2 (e2i = -1: left neighbour's o[3])
   auto hrow0 = [&](int y, float (&h)[4]) {
-    if (edge) hreduce_row<true>(ra, in, y, live, c1, first1, last1, h);
-    else hreduce_row<false>(ra, in, y, 1.0f, c1, false, false, h);
+    if constexpr (ANYW) {
+      hreduce_row_any(ra, in, y, c1, h);
+    } else {
+      if (edge) hreduce_row<true>(ra, in, y, live, c1, first1, last1, h);
+      else hreduce_row<false>(ra, in, y, 1.0f, c1, false, false, h);
+    }
   };
   // level-(l+1) row y1 -> its two horizontally reduced level-(l+2) samples (zero row outside the image)
   auto l1row = [&](int y1, float (&hr)[2]) {
@@ -305,11 +318,21 @@ __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
           for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaf(w0[3][j], k4, o[j]);
         }
       }
+      if constexpr (ANYW) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = j < nv1 ? o[j] : 0.0f;    // columns outside the image: the zero padding of the second pass
+        if (own && y1 >= 2 * r2a && y1 < 2 * r2b) {
+          float* dst = out1 + (int64_t)y1 * a.W1 + c1;
+          if (nv1 == 4) *reinterpret_cast<f4u*>(dst) = f4u{o[0], o[1], o[2], o[3]};
+          else for (int j = 0; j < nv1; ++j) dst[j] = o[j];
+        }
+      } else {
 #ifndef R2_PLAIN_STORES   // level l+1 is next read by a later kernel, long after it left the L2: streaming stores (-1 % on the 4K level-0 pass)
       if (own && y1 >= 2 * r2a && y1 < 2 * r2b) __builtin_nontemporal_store(v4f_{o[0], o[1], o[2], o[3]}, reinterpret_cast<v4f_*>(out1 + (int64_t)y1 * a.W1 + c1));
 #else
       if (own && y1 >= 2 * r2a && y1 < 2 * r2b) *reinterpret_cast<float4*>(out1 + (int64_t)y1 * a.W1 + c1) = make_float4(o[0], o[1], o[2], o[3]);
 #endif
+      }
     } else {
       cold = true;
     }
@@ -318,7 +341,15 @@ __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
     hr[0] = dot5(l2, l3, o[0], o[1], o[2], k0, k1, k2, k3, k4);
     hr[1] = dot5(o[0], o[1], o[2], o[3], rr0, k0, k1, k2, k3, k4);
     if (first1) hr[0] += dot2(o[0], o[1], k1, k0);          // lpyr_dec.py:205 on level l+1
-    if (last1) {                                            // column W2-1 = 2v+1 (W1 % 8 == 0); sic: row parity (:206-209)
+    if constexpr (ANYW) {
+      if (slot2 == 0 || slot2 == 1) {                       // this lane owns column W2-1; sic: row parity (:206-209)
+        const float s1 = e1i == 0 ? o[0] : (e1i == 1 ? o[1] : (e1i == 2 ? o[2] : o[3]));
+        const float s2 = e2i < 0 ? l3 : (e2i == 0 ? o[0] : (e2i == 1 ? o[1] : o[2]));
+        const float base = slot2 == 0 ? hr[0] : hr[1];
+        const float fin = (a.H1 & 1) ? base + dot2(s1, s2, k3, k4) : __builtin_fmaf(s1, k4, base);
+        if (slot2 == 0) hr[0] = fin; else hr[1] = fin;
+      }
+    } else if (last1) {                                     // column W2-1 = 2v+1 (W1 % 8 == 0); sic: row parity (:206-209)
       if (a.H1 & 1) hr[1] += dot2(o[3], o[2], k3, k4);
       else hr[1] = __builtin_fmaf(o[3], k4, hr[1]);
     }
@@ -350,15 +381,24 @@ __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
         for (int j = 0; j < 2; ++j) o2[j] = __builtin_fmaf(w2[3][j], k4, o2[j]);
       }
     }
-    if (own) *reinterpret_cast<float2*>(out2 + (int64_t)r2 * a.W2 + 2 * v) = make_float2(o2[0], o2[1]);
+    if constexpr (ANYW) {
+      if (own) {
+        float* dst = out2 + (int64_t)r2 * a.W2 + 2 * v;
+        if (2 * v < a.W2) dst[0] = o2[0];
+        if (2 * v + 1 < a.W2) dst[1] = o2[1];
+      }
+    } else {
+      if (own) *reinterpret_cast<float2*>(out2 + (int64_t)r2 * a.W2 + 2 * v) = make_float2(o2[0], o2[1]);
+    }
   }
 }
 
-bool reduce2_supported(int H, int W) { return W % 16 == 0 && H >= 8; }
+bool reduce2_supported(int H, int W) { return (W % 16 == 0 || W >= 32) && H >= 8; }
 
 void launch_reduce2(const Reduce2Args& a0, hipStream_t s) {
   Reduce2Args a = a0;
-  const int nq = a.W1 / 4, waves = (nq + R2_LANES - 1) / R2_LANES, bx = (waves + 3) / 4;
+  const bool anyw = a.W % 16 != 0;
+  const int nq = (a.W1 + 3) / 4, waves = (nq + R2_LANES - 1) / R2_LANES, bx = (waves + 3) / 4;
   // equal row segments of at most R2_SEG rows (3 recomputed halo rows each), more of them when the launch would
   // otherwise have fewer than ~4096 blocks (small frames), down to 16 rows
   static const int seg_cap = std::max(4, dev_knob("CVVDP_R2_SEG", R2_SEG));
@@ -367,7 +407,8 @@ void launch_reduce2(const Reduce2Args& a0, hipStream_t s) {
   n_seg = (int)std::max<int64_t>(n_seg, std::min<int64_t>((4096 + per_seg - 1) / per_seg, (a.H2 + 15) / 16));
   a.seg2 = (a.H2 + n_seg - 1) / n_seg;
   dim3 grid(bx, (a.H2 + a.seg2 - 1) / a.seg2, a.n_planes * a.n_img);
-  hipLaunchKernelGGL(k_reduce2, grid, dim3(256), 0, s, a);
+  if (anyw) hipLaunchKernelGGL(k_reduce2<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_reduce2<false>, grid, dim3(256), 0, s, a);
 }
 
 void launch_reduce(const ReduceArgs& a, hipStream_t s) {

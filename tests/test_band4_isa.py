@@ -25,7 +25,7 @@ def test_no_instruction_touches_a_register_with_a_load_in_flight(tmp_path):
     spec.loader.exec_module(chk)
     text = asm.read_text().split("\n")
     starts = [i for i, l in enumerate(text) if l.startswith("_ZN5cvvdp7k_band4") and l.rstrip().split(";")[0].rstrip().endswith(":")]
-    assert len(starts) == 16                      # NCH x HEAT x RAGGED x DUMP
+    assert len(starts) == 20                      # NCH x HEAT x RAGGED x DUMP + the four FEAT instantiations (NCH x RAGGED)
     for s in starts:
         e = next(i for i in range(s, len(text)) if ".end_amdhsa_kernel" in text[i] or text[i].startswith("\t.section"))
         bad, n_loads, n_loops = chk.check_kernel(text[s].split(":")[0], text[s:e])

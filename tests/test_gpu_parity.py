@@ -690,3 +690,24 @@ def test_ml_head_features_against_reference():
         np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
         k += 1
     assert k == 2
+
+
+def test_large_ragged_frames_split_off_their_edge_strips():
+    """W % 8 != 0 on a frame large enough that the aligned strips alone are two GPU-fulls of workgroups: those strips run the
+    aligned instantiation of k_band4 and only the edge strip the RAGGED one, as two launches (core.cpp: split_edge, decided from the
+    clip's nominal block).  The temporal filter is causal, so the first 8 frames of the 40-frame clip (split) must score like the
+    8-frame clip (one RAGGED launch: the path the small ragged shapes are checked on against the oracle) -- different row segments
+    and kernels, same numbers to rounding."""
+    import bench
+    import colorvideovdp_amd as cv
+    H, W = 1444, 2566
+    long = bench.ResidentClip(40, 0, 40, H, W, 60, "u8", torch.device("cuda"))
+    short = bench.ResidentClip(8, 0, 8, H, W, 60, "u8", torch.device("cuda"))
+    assert torch.equal(long.test[:, :, :8], short.test)
+    m = cv.cvvdp(display_name="standard_4k")
+    _, s_long = m.predict_video_source(long)
+    _, s_short = m.predict_video_source(short)
+    np.testing.assert_allclose(s_long["Q_per_ch"][:, :, :8], s_short["Q_per_ch"], rtol=2e-5, atol=1e-7)
+    # and blocks of the long clip do not change a bit (the split is a property of the clip, not of the block)
+    _, s_blk = cv.cvvdp(display_name="standard_4k", block_frames=9).predict_video_source(long)
+    np.testing.assert_array_equal(s_blk["Q_per_ch"], s_long["Q_per_ch"])

@@ -1,5 +1,7 @@
 #!/bin/bash
 # throughput on other shapes (64 frames, u8, resident): tools/shape_bench.sh "1366x768 1360x768 854x480 848x480 ..."
+# per shape: wall time of 10 unprofiled calls, then the per-kernel-family milliseconds of 5 profiled calls (HIP events; the
+# edge strips of a ragged width run in the main stream while profiling, so the families add up to a little more than the wall time)
 python - "$@" <<'PY'
 import sys, time, torch
 sys.path.insert(0, ".")
@@ -15,5 +17,11 @@ for shape in (sys.argv[1:] or ["1366x768", "1360x768", "854x480", "848x480", "19
     for _ in range(10):
         jod, _ = m.predict_video_source(clip)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-    print(f"{shape}: {dt * 1e3:.3f} ms per 64 frames, {W * H * 64 / dt / 1e9:.2f} Gpixel/s, JOD {float(jod):.4f}")
+    m.profile(True)
+    for _ in range(5):
+        m.predict_video_source(clip)
+    torch.cuda.synchronize()
+    prof = {k: round(v[0] / 5, 3) for k, v in m.profile_read().items() if v[0] > 0}
+    m.profile(False)
+    print(f"{shape}: {dt * 1e3:.3f} ms per 64 frames, {W * H * 64 / dt / 1e9:.2f} Gpixel/s, JOD {float(jod):.4f}  kernels {prof}")
 PY

@@ -711,3 +711,33 @@ def test_large_ragged_frames_split_off_their_edge_strips():
     # and blocks of the long clip do not change a bit (the split is a property of the clip, not of the block)
     _, s_blk = cv.cvvdp(display_name="standard_4k", block_frames=9).predict_video_source(long)
     np.testing.assert_array_equal(s_blk["Q_per_ch"], s_long["Q_per_ch"])
+
+
+def test_8k_pq_full_temporal_window_heatmap_and_distogram_against_reference():
+    """configs[4] at depth (missing #4): 17 frames of the 7680x4320 PQ clip, so that frame 16 is scored with 16 DISTINCT
+    real predecessors (the 2-frame 8K fixtures only see replicate-padded windows), with the supra-threshold heat map and the
+    distogram arrays, all against the real reference (oracle/make_goldens_8k17.py: 24 minutes of the reference's CPU path)."""
+    import bench
+    import colorvideovdp_amd as cv
+    g = load_golden("bench_8k_pq_heat_17f")
+    W, H, F = int(g["width"]), int(g["height"]), int(g["frames"])
+    clip = bench.ResidentClip(F, 0, F, H, W, float(g["fps"]), "u8", torch.device("cuda"), gen="cpu")
+    if (clip.checksum_test, clip.checksum_ref) != (int(g["checksum_test"]), int(g["checksum_ref"])):
+        pytest.fail("this torch build's CPU generator does not reproduce the fixture's synthetic frames (checksum mismatch)")
+    m = cv.cvvdp(display_name=str(g["display"]), heatmap=str(g["heatmap_mode"]))
+    jod, stats = m.predict_video_source(clip)
+    assert abs(float(jod) - float(g["jod"])) <= JOD_TOL
+    np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(stats["Q_per_ch"][:, :, 16], g["Q_per_ch"][:, :, 16], rtol=2e-4, atol=2e-6)   # the frame with the full window
+    hm = stats["heatmap"]
+    assert tuple(hm.shape) == (1, 3, F, H, W) and hm.dtype == torch.float16
+    keep = [int(k) for k in g["heatmap_frames"]]
+    d = np.abs(hm[0][:, keep, ::16, ::16].numpy().astype(np.float32) - g["heatmap_ds"].astype(np.float32))
+    assert (d > 2e-3).mean() < 1e-3 and d.max() <= 2e-2, ((d > 2e-3).mean(), d.max())
+    means = np.array([float(hm[0, :, f].float().mean()) for f in range(F)], dtype=np.float32)
+    np.testing.assert_allclose(means, g["heatmap_frame_means"], atol=2e-4)
+    st = {k: v for k, v in stats.items() if k != "heatmap"}
+    for jm, key in ((None, "disto_auto"), (10, "disto_10")):               # cvvdp_metric.py:1160-1192: what imshow is handed
+        panels, _ = m.distogram_data(st, jod_max=jm)
+        assert panels.shape == g[key].shape
+        np.testing.assert_allclose(panels, g[key], rtol=5e-4, atol=2e-6)

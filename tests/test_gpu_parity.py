@@ -719,7 +719,7 @@ def test_8k_pq_full_temporal_window_heatmap_and_distogram_against_reference():
     distogram arrays, all against the real reference (oracle/make_goldens_8k17.py: 24 minutes of the reference's CPU path)."""
     import bench
     import colorvideovdp_amd as cv
-    g = load_golden("bench_8k_pq_heat_17f")
+    g = load_golden("deep_8k_pq_heat_17f")
     W, H, F = int(g["width"]), int(g["height"]), int(g["frames"])
     clip = bench.ResidentClip(F, 0, F, H, W, float(g["fps"]), "u8", torch.device("cuda"), gen="cpu")
     if (clip.checksum_test, clip.checksum_ref) != (int(g["checksum_test"]), int(g["checksum_ref"])):

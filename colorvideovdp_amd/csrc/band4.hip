@@ -138,6 +138,9 @@ __global__ __launch_bounds__(64 * NCH, FEAT ? 2 : 3) void k_band4(BandArgs a) {
   float xw0 = a.xw[0 * 4 + c], xw1 = a.xw[1 * 4 + c], xw2 = a.xw[2 * 4 + c], xw3 = a.xw[3 * 4 + c];
   float m1c = a.m1[c];                             // 1 - sum_k xw[k][c] * eps^q_k: the "1 +" of the mask and the eps terms of safe_pow
   float inv_dmax = a.inv_dmax;
+  if constexpr (RAGGED && !HEAT && !DUMP && !FEAT) {   // (the ragged instantiation has about eight VGPRs to spare: SGPR spills 73 -> 53,
+    B4_IN_VGPR(xw1); B4_IN_VGPR(xw2); B4_IN_VGPR(xw3); B4_IN_VGPR(m1c); B4_IN_VGPR(inv_dmax); B4_IN_VGPR(ind_k0);   // lane reads per row pair 88 -> 68)
+  }
   if constexpr (!RAGGED) {   // (the ragged instantiation is short of VGPRs instead)
     B4_IN_VGPR(ind_k0); B4_IN_VGPR(xw1); B4_IN_VGPR(xw2); B4_IN_VGPR(xw3); B4_IN_VGPR(m1c); B4_IN_VGPR(inv_dmax);
     if constexpr ((!HEAT && !DUMP) || FEAT) {   // (those instantiations have no VGPRs to spare; FEAT runs two blocks per CU: 256)

@@ -142,18 +142,31 @@ __device__ __forceinline__ void hreduce_row_any(const ReduceArgs& a, const float
   const int ix = 2 * ox - 4;
   const float* row = img + (int64_t)min(max(y, 0), a.H - 1) * a.W;
   const float my = (y >= 0 && y < a.H) ? 1.0f : 0.0f;
+  // Every lane issues the same four 16-byte loads, a group that leaves the image at a clamped address (ix is a multiple of 4, so
+  // a group is left of column 0 as a whole; at the right border it is clamped to the row's last four samples).  Only the lanes
+  // at a border then repair their groups in registers: zero padding left of column 0 and from column W on, the clamped group
+  // shifted into place.  (Sample-by-sample loads for those lanes cost 16 more load instructions for the whole wave -- and at
+  // widths of a few hundred pixels most waves hold a border lane.)
   float v[16];
-  if (ix >= 0 && ix + 16 <= a.W) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f4u t = *reinterpret_cast<const f4u*>(row + min(max(ix + 4 * q, 0), a.W - 4));
+    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  }
+  if (ix < 0 || ix + 16 > a.W) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f4u t = *reinterpret_cast<const f4u*>(row + ix + 4 * q);
-      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-    }
-  } else {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int x = ix + e;
-      v[e] = row[min(max(x, 0), a.W - 1)] * ((x >= 0 && x < a.W) ? 1.0f : 0.0f);
+      const int x = ix + 4 * q;
+      const int sh = x - (a.W - 4);                       // > 0: the group starts sh samples right of the clamped load
+      const float r1 = v[4 * q + 1], r2 = v[4 * q + 2], r3 = v[4 * q + 3];
+      if (x < 0 || sh >= 4) {
+        v[4 * q] = v[4 * q + 1] = v[4 * q + 2] = v[4 * q + 3] = 0.0f;
+      } else if (sh > 0) {
+        v[4 * q] = sh == 1 ? r1 : (sh == 2 ? r2 : r3);
+        v[4 * q + 1] = sh == 1 ? r2 : (sh == 2 ? r3 : 0.0f);
+        v[4 * q + 2] = sh == 1 ? r3 : 0.0f;
+        v[4 * q + 3] = 0.0f;
+      }
     }
   }
   const float k0 = a.k[0] * my, k1 = a.k[1] * my, k2 = a.k[2] * my, k3 = a.k[3] * my, k4 = a.k[4] * my;

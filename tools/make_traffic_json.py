@@ -17,7 +17,7 @@ KERNELS = {
     # key: (substring of the kernel name, workgroups of the level-0 launch, algorithmic bytes per launch, what they are)
     "temporal_fir": ("k_fir_rot<3, 17>", None, PIX * (24 + 32.0), "24 B/pixel in (fp32 RGB, test + reference) + 32 B/pixel out (8 level-0 planes)"),
     "pyr_reduce_l0": ("k_reduce2", None, PIX * (32 + 8 + 2.0), "levels 0 -> 1 -> 2 in one pass: 32 B/pixel in, 8 + 2 B/pixel out"),
-    "band_level0": ("k_band4<4, false, false, false>", None, PIX * 40.0, "g0 (32 B/pixel) + g1 (8 B/pixel) in; partial sums out"),
+    "band_level0": ("k_band4<4, false, false, false, false>", None, PIX * 40.0, "g0 (32 B/pixel) + g1 (8 B/pixel) in; partial sums out"),
 }
 
 

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64) void k_finalize(FinalizeArgs a) {
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if (lane == 0) {
     const int f = item / a.batch, b = item - f * a.batch;
-    const float mean = (float)(s / (double)a.P);
+    const float mean = (float)(s / (double)a.P - a.sub_per_term);
     a.q_out[(((int64_t)b * a.nch + c) * a.q_frames + a.q_frame_offset + f) * a.q_levels + a.level] =
         sqrtf(mean + kEps) - sqrtf(kEps);
   }

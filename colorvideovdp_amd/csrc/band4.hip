@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64 * NCH, FEAT ? 2 : 3) void k_band4(BandArgs a) {
     f4 q3 = f4{{0.0f, 0.0f, 0.0f, 0.0f}};
     if constexpr (NCH == 4) q3 = lds_read4(&s_q[3][4 * j]);
     const f4 d = lds_read4(&s_d[k7][c][4 * j - B4_HALO]);
-    float D[4];
+    float D[4], De[4];                 // D (heat map, dump, features) and D + eps (the pooled term)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {      // two column pairs: the mask sum and the clamp denominator as packed FMAs (-1.5 %; packing the
                                        // expand or the vertical combine as well costs registers: slower, profiles/r02_dev_notes.txt)
@@ -322,14 +322,19 @@ __global__ __launch_bounds__(64 * NCH, FEAT ? 2 : 3) void k_band4(BandArgs a) {
       // Du = X/(1+M); D = dmax*Du/(dmax+Du) = X / ((1+M) + X/dmax): one reciprocal (:855-856, :949-950); s_d holds |T'-R'| + eps
       const v2f X = {fast_pow(d.v[2 * h], mask_p) - eps_p, fast_pow(d.v[2 * h + 1], mask_p) - eps_p};
       const v2f T = X * inv_dmax + M1;
-      D[2 * h] = X.x * fast_rcp(T.x); D[2 * h + 1] = X.y * fast_rcp(T.y);
+      const float r0 = fast_rcp(T.x), r1 = fast_rcp(T.y);
+      De[2 * h] = __builtin_fmaf(X.x, r0, kEps); De[2 * h + 1] = __builtin_fmaf(X.y, r1, kEps);
+      if constexpr (HEAT || DUMP || FEAT) { D[2 * h] = X.x * r0; D[2 * h + 1] = X.y * r1; }
+      else { D[2 * h] = 0.0f; D[2 * h + 1] = 0.0f; }
     }
-    if (ragged_blk) {                                              // columns right of the image do not exist
+    if (ragged_blk) {                                              // columns right of the image do not exist: no term
 #pragma unroll
-      for (int i = 1; i < 4; ++i) D[i] = i < n_valid ? D[i] : 0.0f;
+      for (int i = 1; i < 4; ++i) { D[i] = i < n_valid ? D[i] : 0.0f; De[i] = i < n_valid ? De[i] : 0.0f; }
     }
+    // safe_pow(D, 2) = (D + eps)^2 - eps^2 (cvvdp_metric.py:1032-1050, beta = 2): the lanes sum (D + eps)^2 -- one FMA per pixel -- and
+    // k_finalize takes the eps^2 of the level's H*W terms off the mean in double (FinalizeArgs::sub_per_term)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc += D[i] * (D[i] + 2.0f * kEps);   // (D+eps)^2 - eps^2
+    for (int i = 0; i < 4; ++i) acc = __builtin_fmaf(De[i], De[i], acc);
     if constexpr (FEAT) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { f_d[i] += D[i]; f_d2[i] = __builtin_fmaf(D[i], D[i], f_d2[i]); }
@@ -549,7 +554,7 @@ __global__ __launch_bounds__(64 * NCH, FEAT ? 2 : 3) void k_band4(BandArgs a) {
       // weight of slot s when the newest row sits in `slot`: window position j = (s - slot - 1) mod 13 -> wr[]
       // is kept rotated so that wr[s] is exactly that weight; columns (0,1) and (2,3) share one packed FMA
       if (yc >= ys) {                                     // (the first twelve rows of a segment only fill the window)
-        v2f va = 0.0f, vb = 0.0f;
+        v2f va = kEps, vb = kEps;                         // safe_pow's "+ eps" (cvvdp_metric.py:849) as the accumulators' start value
 #pragma unroll
         for (int sdx = 0; sdx < B4_BW; ++sdx) {
           const v2f wa = {winA[2 * sdx], winA[2 * sdx + 1]}, wb = {winB[2 * sdx], winB[2 * sdx + 1]};
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(64 * NCH, FEAT ? 2 : 3) void k_band4(BandArgs a) {
         const float v[4] = {va.x, va.y, vb.x, vb.y};
         float Mq[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Mq[i] = fast_pow(v[i] + kEps, qc);   // cvvdp_metric.py:849; "- eps^q" is inside m1c
+        for (int i = 0; i < 4; ++i) Mq[i] = fast_pow(v[i], qc);          // (blur*10^mask_c + eps)^q_c; "- eps^q" is inside m1c
         lds_write4(&s_q[c][4 * j], Mq);
       }
     }

@@ -274,6 +274,7 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
     f.partial = a.partial; f.items = items; f.nblk = lv.n_strip * lv.n_seg; f.nch = nch; f.P = (int)lv.P;
     f.q_out = h->ws + h->q_off; f.q_frames = h->c.n_frames; f.q_levels = L; f.q_frame_offset = q_frame_offset;
     f.level = l; f.batch = B;
+    f.sub_per_term = lv.vec4 ? (double)kEps * (double)kEps : 0.0;
     launch_finalize(f, s);
   }
   if (int e = check_launch(h, "band")) return e;

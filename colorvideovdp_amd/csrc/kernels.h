@@ -199,6 +199,7 @@ struct FinalizeArgs {
   const float* partial;  // [items][nblk][4]
   int32_t items, nblk, nch, P;
   float* q_out; int32_t q_frames, q_levels, q_frame_offset, level, batch;
+  double sub_per_term;   // k_band4 sums (D + eps)^2 over the level's P pixels: eps^2 per term comes off the mean; k_band sums (D+eps)^2 - eps^2: 0
 };
 void launch_finalize(const FinalizeArgs& a, hipStream_t s);
 

@@ -34,6 +34,9 @@ timeout 900 python bench.py --workload 8k256pq --cpu-frames 0 --steps 2 --warmup
 timeout 900 python bench.py --dtype u8 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --dtype yuv420p8 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --dtype yuv420p10 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
+# 120 fps: 31-tap temporal filters (k_fir_fused, 30 halo frames); kernel_roofline.temporal_fir of this line is its roofline figure
+timeout 900 python bench.py --fps 120 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
+timeout 900 python bench.py --fps 120 --dtype u8 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 # 3b. the multi-rank path on this one GPU: 2 ranks over gloo sharing the device (shard plan, halo frames, gather, rank-0 line),
 #     five runs per sharded workload, 120 s limit each: every run must print its JSON line (tests/test_bench_multirank.py)
 : > $OUT/${TAG}_two_ranks_one_gpu_gloo.log
@@ -49,6 +52,7 @@ done
 # 3c. heat-map path (whole-clip tensor), shard-halo cost, other shapes
 timeout 900 python tools/heatmap_bench.py 4k 32 > $OUT/${TAG}_heatmap_bench.txt 2>&1
 timeout 900 python tools/heatmap_bench.py 8k 24 >> $OUT/${TAG}_heatmap_bench.txt 2>&1
+( timeout 600 python tools/features_bench.py 3840x2160; timeout 600 python tools/features_bench.py 1920x1080 ) 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_features_bench.txt
 timeout 600 python tools/shard_halo_bench.py > $OUT/${TAG}_shard_halo_bench.txt 2>&1
 timeout 600 tools/shape_bench.sh 2560x1440 1920x1080 1366x768 1360x768 854x480 848x480 > $OUT/${TAG}_shape_bench.txt 2>&1
 # 4. GPU test log

@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # The CPU frame generator runs many OpenMP teams; idle OpenMP workers that keep spinning afterwards steal the cores the
 # HIP runtime's launch path needs (measured: kernels queue late and a 19 ms step takes 40 ms).  Must be set before torch loads.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # multi-process GPU work: the host driver only supports dmabuf IPC (RCCL needs it)
 os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 os.environ.setdefault("GOMP_SPINCOUNT", "0")
 

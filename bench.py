@@ -245,20 +245,21 @@ def cpu_baseline(W, H, fps, display, n_frames, frames=None):
                         "0.63 Mpixel/s on 3840x2160 x 4 frames"), float(jod), t, r
 
 
-def lockstep_spinup(step, seconds, world, flag_device, sync=lambda: None):
+def lockstep_spinup(step, seconds, world, flag_device, sync=lambda: None, collective=None):
     """Untimed spin-up: run step() for about `seconds`, the SAME number of times on every rank.  Multi-rank, every step() ends in
     a collective (the all-gather of Q_per_ch), so a per-rank clock must not decide when to stop: ranks enter the loop at different
     times and would leave it after different iteration counts -- one rank then sits in barrier() while another is still in
     all_gather, and the job hangs (round 2's bench did exactly that).  The ranks line up at a barrier first, and after every
     step rank 0's clock decides for everybody (one broadcast word).  Returns the number of steps run."""
     import torch.distributed as dist
-    if world > 1:
+    collective = world > 1 if collective is None else collective
+    if collective:
         dist.barrier()
     t0 = time.perf_counter()
     n = 0
     while True:
         more = torch.tensor([1 if time.perf_counter() - t0 < seconds else 0], dtype=torch.int32, device=flag_device)
-        if world > 1:
+        if collective:
             dist.broadcast(more, src=0)
         if int(more.item()) == 0:
             return n
@@ -299,7 +300,11 @@ def main():
     backend = os.environ.get("CVVDP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # CVVDP_BENCH_FORCE_DIST=1 (test hook, launched through torch.distributed.run with one process): initialise the process group and run
+    # every collective of the multi-rank path -- barrier, broadcast, the all-gather of Q_per_ch, the MAX all-reduce -- with world size 1.
+    # With the default backend that is the RCCL code path on the one GPU of a test box (tests/test_bench_multirank.py).
+    dist_on = world > 1 or os.environ.get("CVVDP_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=device)
@@ -332,7 +337,7 @@ def main():
         clip = ResidentYuvClip(n_total, lo, first + count, H, W, fps, 8 if dtype.endswith("p8") else 10, device)
     else:
         clip = ResidentClip(n_total, lo, first + count, H, W, fps, dtype, device, gen=gen, pq_range=args.workload == "8k256pq")
-    if world > 1:
+    if dist_on:
         m.set_frame_sharding("world")
     sink = HeatmapFrameMeans(uint8=args.heatmap_format == "u8") if heat is not None else None      # the heat map leaves the GPU block by block (bounded host memory)
 
@@ -344,13 +349,13 @@ def main():
     # on a fresh box: the VALU-bound kernels ran 1.6-2x slower through the first ~7 steps.  So the device is first kept busy for
     # about a second (untimed, like the warm-up steps that follow).
     n_spin = lockstep_spinup(step, float(os.environ.get("CVVDP_BENCH_SPINUP_S", "1.0")), world,
-                             device if backend == "nccl" else torch.device("cpu"), torch.cuda.synchronize)
+                             device if backend == "nccl" else torch.device("cpu"), torch.cuda.synchronize, collective=dist_on)
     if sink is not None:
         sink.frames_seen = 0          # count the streamed heat-map frames of the warm-up + timed steps only
     for _ in range(args.warmup):
         jod, stats = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     if not args.no_profile:
         m.profile(True)
@@ -359,17 +364,17 @@ def main():
     for _ in range(args.steps):
         jod, stats = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     prof = None if args.no_profile else m.profile_read()
     m.profile(False)
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
     if rank != 0:
-        if world > 1:
+        if dist_on:
             torch.distributed.destroy_process_group()
         return
     pixels = W * H * n_total * args.steps
@@ -390,6 +395,9 @@ def main():
                    "heatmap": heat or "none", "frame_generator": gen, "block_frames": getattr(m, "last_block_frames", None)},
         "jod": round(float(jod), 5), "spinup_steps": n_spin,
     }
+    if dist_on:
+        out["config"]["collectives"] = {"backend": torch.distributed.get_backend(), "world": world,
+                                        "per_step": "one all-gather of the Q_per_ch shards", "spin_up": "barrier + one broadcast word per step"}
     if golden is not None and gen == "cpu":
         if (clip.checksum_test, clip.checksum_ref) == (int(golden["checksum_test"]), int(golden["checksum_ref"])):
             q, qr = stats["Q_per_ch"].astype(np.float64), golden["Q_per_ch"].astype(np.float64)
@@ -474,7 +482,7 @@ def main():
         hjod, _ = cv.cvvdp(display_name=display, device=device).predict(t, r, dim_order="BCFHW", frames_per_second=fps)
         out["jod_delta_vs_oracle_sample"] = float(abs(float(hjod) - ojod))
     print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

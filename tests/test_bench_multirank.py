@@ -40,3 +40,21 @@ def test_two_rank_bench_prints_its_line_every_time(workload, extra, frames_total
         assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["config"]["frames_total"] == frames_total
         assert d["value"] > 0 and 0 < d["jod"] <= 10
         assert d["spinup_steps"] >= 1
+
+
+def test_rccl_collectives_run_with_one_rank():
+    """The box has one GPU and RCCL refuses two ranks on one device, so the RCCL flavour of the multi-rank path cannot be run with
+    world size 2 here.  What can: the same code with ONE rank and the default backend ("nccl" = RCCL) -- process-group set-up with
+    device_id, the barrier, the int32 broadcast of the spin-up, the all-gather of the Q_per_ch shard on device tensors, the float64
+    MAX all-reduce of the step time -- through bench.py's CVVDP_BENCH_FORCE_DIST hook."""
+    env = dict(os.environ, CVVDP_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", CVVDP_BENCH_SPINUP_S="0.3")
+    env.pop("CVVDP_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(30900 + (os.getpid() % 1500)), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--cpu-frames", "0", "--gen", "gpu", "--frames", "24"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=180, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["config"]["collectives"]["backend"] == "nccl" and d["n_gpus"] == 1 and d["spinup_steps"] >= 1 and 0 < d["jod"] <= 10

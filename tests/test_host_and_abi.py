@@ -151,3 +151,21 @@ def test_heatmap_uint8_conversion_is_the_reference_writers_float16_product():
     np.testing.assert_array_equal(got, want)
     f32 = (np.clip(frames[0].permute(1, 2, 3, 0).float().numpy(), 0.0, 1.0) * 255.0).astype(np.uint8)
     assert (f32 != want).any()                                                  # the fp32 product is NOT the same thing
+
+
+def test_product_library_has_no_development_knobs_and_the_binding_loads_only_it(tmp_path):
+    """tuning knobs that change launch geometry (and the last bits of Q_per_ch) are compiled out of the product
+    build; CVVDP_LIB (load another library) is honoured only together with CVVDP_DEV_KNOBS=1."""
+    import subprocess
+    import sys
+    from colorvideovdp_amd import _capi
+    assert _capi.lib().cvvdp_build_flags() & _capi.BUILD_DEV_KNOBS == 0
+    src = open(os.path.join(ROOT, "colorvideovdp_amd", "csrc", "core.cpp")).read()
+    assert "getenv" not in src                                   # every knob goes through kernels.h::dev_knob
+    code = "from colorvideovdp_amd import _capi; print(_capi.LIB_PATH)"
+    env = dict(os.environ, CVVDP_LIB=str(tmp_path / "other.so"), PYTHONPATH=ROOT)
+    env.pop("CVVDP_DEV_KNOBS", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip()
+    assert out.endswith(os.path.join("colorvideovdp_amd", "libcvvdp_hip.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, CVVDP_DEV_KNOBS="1"), capture_output=True, text=True, timeout=120).stdout.strip()
+    assert out == str(tmp_path / "other.so")

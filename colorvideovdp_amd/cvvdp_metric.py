@@ -265,6 +265,8 @@ class cvvdp(vq_metric):
         return hasattr(vs, "get_raw_yuv_block") or hasattr(vs, "get_raw_block") or isinstance(vs, video_source_array)
 
     def _predict_video_source(self, vid_source, height, width, N_frames, is_image, heatmap_sink=None):
+        if getattr(self, "_profile_per_call", False):      # (the handle may have been re-made since profile() was called)
+            _capi.check(self._handle, _capi.lib().cvvdp_profile_enable(self._handle, 1), "cvvdp_profile_enable")
         first, count = 0, N_frames
         group = None
         sharded = False
@@ -296,6 +298,8 @@ class cvvdp(vq_metric):
                 stats["heatmap"] = heatmap
             if count != N_frames:
                 stats["heatmap_frame_range"] = (first, first + count)
+        if getattr(self, "_profile_per_call", False):
+            stats["kernel_ms"] = {name: ms for name, (ms, _n) in self.profile_read().items()}
         return (Q_jod.squeeze(), stats)
 
     # ------------------------------------------------------------------ block planning
@@ -792,7 +796,12 @@ class cvvdp(vq_metric):
         off = ptr.value - self._ws.data_ptr()
         return self._ws[off:off + n.value * 4].view(torch.float32)
 
-    def profile(self, enable=True):
+    def profile(self, enable=True, per_call=False):
+        """HIP-event timing of the kernel families ("hipEvent timings exposed in stats").  per_call=True: every
+        predict() / predict_video_source() afterwards carries stats["kernel_ms"] = {family: milliseconds of that call}
+        (the events are read -- one host wait -- when the call returns).  per_call=False (bench.py): the times accumulate until
+        profile_read()."""
+        self._profile_per_call = bool(enable and per_call)
         _capi.check(self._handle, _capi.lib().cvvdp_profile_enable(self._handle, int(enable)), "cvvdp_profile_enable")
 
     def profile_read(self):

@@ -741,3 +741,21 @@ def test_8k_pq_full_temporal_window_heatmap_and_distogram_against_reference():
         panels, _ = m.distogram_data(st, jod_max=jm)
         assert panels.shape == g[key].shape
         np.testing.assert_allclose(panels, g[key], rtol=5e-4, atol=2e-6)
+
+
+def test_kernel_timings_in_stats_when_asked_for():
+    """HIP-event timings of the kernel families exposed in `stats` (opt-in: the reference's stats keys stay as they are)."""
+    g = load_golden("vid_u8_72x128x12_60_fhd")
+    meta = dict(g["meta"], heatmap=None)
+    m = _metric(meta)
+    t, r = _inputs(g)
+    _, s0 = m.predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+    assert "kernel_ms" not in s0
+    m.profile(True, per_call=True)
+    _, s1 = m.predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+    km = s1["kernel_ms"]
+    assert set(km) >= {"temporal_fir", "pyr_reduce", "band_level0", "band_rest"} and km["temporal_fir"] > 0 and km["band_level0"] > 0
+    np.testing.assert_array_equal(s1["Q_per_ch"], s0["Q_per_ch"])
+    m.profile(False)
+    _, s2 = m.predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+    assert "kernel_ms" not in s2

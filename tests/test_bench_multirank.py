@@ -16,6 +16,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUNS = 5
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _torch_is_paged_in():
+    """The first `import torch` on a fresh box takes a minute or two while the image pages in; that is not what the 120 s limit of
+    a bench run is there to catch.  This module sorts first among the GPU tests, so pay for it here, once, outside the limit."""
+    subprocess.run([sys.executable, "-c", "import torch, torch.distributed"], check=True, timeout=900)
+
+
 def _bench_two_ranks(extra, port):
     env = dict(os.environ, CVVDP_BENCH_BACKEND="gloo", CVVDP_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1",
                HSA_ENABLE_IPC_MODE_LEGACY="0", CVVDP_BENCH_SPINUP_S="0.5")

@@ -165,7 +165,7 @@ def test_product_library_has_no_development_knobs_and_the_binding_loads_only_it(
     code = "from colorvideovdp_amd import _capi; print(_capi.LIB_PATH)"
     env = dict(os.environ, CVVDP_LIB=str(tmp_path / "other.so"), PYTHONPATH=ROOT)
     env.pop("CVVDP_DEV_KNOBS", None)
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.strip()
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900).stdout.strip()
     assert out.endswith(os.path.join("colorvideovdp_amd", "libcvvdp_hip.so"))
-    out = subprocess.run([sys.executable, "-c", code], env=dict(env, CVVDP_DEV_KNOBS="1"), capture_output=True, text=True, timeout=120).stdout.strip()
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, CVVDP_DEV_KNOBS="1"), capture_output=True, text=True, timeout=900).stdout.strip()
     assert out == str(tmp_path / "other.so")

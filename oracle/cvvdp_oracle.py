@@ -354,7 +354,7 @@ class Oracle:
     """predict()/predict_video_source() of class cvvdp (cvvdp_metric.py:108-441), CPU, block = 1 frame."""
 
     def __init__(self, display_name="standard_4k", heatmap=None, temp_padding="replicate", bundle=None, keep=False,
-                 photometry=None, geometry=None):
+                 photometry=None, geometry=None, features=False):
         self.bundle = bundle or load_bundle()
         self.display = Display(display_name, self.bundle, photometry=photometry, geometry=geometry)
         self.ppd = self.display.ppd
@@ -363,6 +363,9 @@ class Oracle:
         self.temp_padding = temp_padding
         self.keep = keep  # keep intermediates of the LAST processed block in self.dbg
         self.dbg = {}
+        # features=True: predict() also collects what cvvdp_ml_base.extract_features returns (cvvdp_ml_metric.py:193-277):
+        # self.features[band] = list (one entry per frame / per image) of [B, 1, cells_y, cells_x, channels, 6] tensors
+        self.features = [] if features else None
         p = self.bundle["cvvdp_parameters"]
         T = torch.as_tensor  # cvvdp_metric.py:154-226: every scalar becomes a tensor of its JSON type
         self.mask_p, self.mask_c = T(p["mask_p"]), T(p["mask_c"])
@@ -477,6 +480,24 @@ class Oracle:
                 S[:, cc:cc + 1] = self.csf.sensitivity(row, lL) * 10.0 ** (self.sens_corr / 20.0)
             D = torch.abs(Tf - Rf) * S if base else self.masking(Tf, Rf, S)
             Q[:, :, :, bb] = self.lp_norm(D, self.beta, dim=(-2, -1), normalize=True, keepdim=False)
+            if self.features is not None:
+                # cvvdp_ml_base.process_block_of_frames, cvvdp_ml_metric.py:351-358: cvvdp_feature_pooling(ceil(pix_per_deg)) of
+                # |T_f|*S, |R_f|*S and D (:77-107: AvgPool2d(fs, ceil_mode=True) of x and x**2, variance = E[x^2] - mean^2),
+                # laid out [batch, frames, cells_y, cells_x, channels, 6]
+                fs = int(math.ceil(self.ppd))
+                pool = torch.nn.AvgPool2d((fs, fs), ceil_mode=True)
+
+                def ap(x):                                   # cvvdp_avg_pool (:62-73): batch and channel merged for the 2-D pool
+                    v = x.reshape((-1,) + tuple(x.shape[2:]))
+                    y = pool(v)
+                    return y.reshape(tuple(x.shape[0:2]) + tuple(y.shape[1:]))
+
+                order = [0, 2, 3, 4, 1]
+                cols = []
+                for x in (torch.abs(Tf) * S, torch.abs(Rf) * S, D):
+                    mean = ap(x).permute(order)
+                    cols += [mean, ap(x ** 2).permute(order) - mean ** 2]
+                self.features[bb].append(torch.stack(cols, dim=5))
             if self.keep:
                 self.dbg["S"].append(S)
                 self.dbg["D"].append(D)
@@ -520,6 +541,8 @@ class Oracle:
         is_image = Ftot == 1
         height, freqs = band_frequencies(W, H, self.ppd)
         levels = height + 1
+        if self.features is not None:
+            self.features = [[] for _ in range(levels)]
         rho_band = freqs.copy()
         rho_band[levels - 1] = 0.1  # Q2, cvvdp_metric.py:685-686
         n_frames = Ftot - first_frame if n_frames is None else n_frames
@@ -572,6 +595,8 @@ class Oracle:
                     hm_out[:, :, fo:fo + 1] = self._colour(hm, Rb[:, 0])
         stats = {"Q_per_ch": Qpc.numpy(), "rho_band": rho_band, "frames_per_second": frames_per_second,
                  "width": W, "height": H, "N_frames": n_frames}
+        if self.features is not None:      # [B, F, cells_y, cells_x, channels, 6] per band, like extract_features (:262-277)
+            stats["features"] = [torch.cat(f, dim=1).numpy() for f in self.features]
         if self.do_heatmap:
             stats["heatmap"] = hm_out
         return self.pool(Qpc), stats

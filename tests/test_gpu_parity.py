@@ -759,3 +759,33 @@ def test_kernel_timings_in_stats_when_asked_for():
     m.profile(False)
     _, s2 = m.predict(t, r, dim_order=meta["dim_order"], frames_per_second=meta["fps"])
     assert "kernel_ms" not in s2
+
+
+@pytest.mark.parametrize("W,H,F,disp", [(683, 389, 3, "standard_fhd"), (1366, 768, 2, "standard_4k"), (250, 131, 1, "standard_fhd")])
+def test_fused_features_on_ragged_multi_strip_frames(W, H, F, disp):
+    """The FEAT instantiation of k_band4 (column sums per piece of a cell row + k_feature_finish) where the small fixtures do not
+    reach: widths that are not a multiple of 8 (RAGGED + FEAT), several strips (cells that straddle a strip seam), several row
+    segments (cell rows cut into pieces), levels of odd size; against the oracle's feature pooling, which is pinned to the real
+    reference's extract_features (tests/test_oracle_vs_golden.py)."""
+    import colorvideovdp_amd as cv
+    from oracle import cvvdp_oracle as orc
+    rng = np.random.default_rng(W)
+    y, x = np.mgrid[0:H, 0:W]
+    ref = np.stack([np.stack([0.45 + 0.3 * np.sin(2 * np.pi * (3.1 * x / W + f / 9.0) + c) * np.cos(2 * np.pi * 2.3 * y / H) for c in range(3)])
+                    for f in range(F)], axis=1)[None]
+    test = np.clip(ref + 0.05 * rng.standard_normal(ref.shape), 0, 1)
+    ref8, test8 = np.round(ref * 255).astype(np.uint8), np.round(test * 255).astype(np.uint8)
+    fps = 0 if F == 1 else 30
+    o = orc.Oracle(display_name=disp, features=True)
+    _, ostats = o.predict(test8, ref8, dim_order="BCFHW", frames_per_second=fps)
+    m = cv.cvvdp(display_name=disp, block_frames=2)
+    vs = cv.video_source_array(test8, ref8, fps, dim_order="BCFHW", display_photometry=m.display_photometry)
+    feats, _ = m.extract_features(vs)
+    assert len(feats) == len(ostats["features"])
+    for bb, (f, want) in enumerate(zip(feats, ostats["features"])):
+        got = f.cpu().numpy()
+        assert got.shape == want.shape, (bb, got.shape, want.shape)
+        for q in (0, 2, 4):
+            np.testing.assert_allclose(got[..., q], want[..., q], rtol=5e-4, atol=2e-6, err_msg=f"band {bb} mean {q}")
+            scale = np.abs(want[..., q]) ** 2 + np.abs(want[..., q + 1])
+            assert np.all(np.abs(got[..., q + 1] - want[..., q + 1]) <= 2e-3 * scale + 1e-7), f"band {bb} var {q + 1}"

@@ -135,3 +135,29 @@ def test_oracle_reproduces_the_documented_hdr_known_answer():
     assert round(float(jod), 3) == round(float(g["documented_jod"]), 3) == 8.696
     assert abs(float(jod) - float(g["jod"])) <= 2e-5
     np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-5, atol=2e-7)
+
+
+def test_oracle_features_against_reference():
+    """The oracle's restatement of the ML heads' feature pooling (cvvdp_ml_metric.py:77-107, :351-358) against the real reference's
+    extract_features (tests/golden/features.npz, oracle/make_goldens_features.py): the GPU suite uses it on shapes the fixtures
+    do not cover (ragged widths, several strips and segments)."""
+    from conftest import load_golden
+    from oracle import cvvdp_oracle as orc
+    gf = load_golden("features")
+    k = 0
+    while f"case{k}" in gf:
+        g = load_golden(str(gf[f"case{k}"]))
+        meta = g["meta"]
+        o = orc.Oracle(display_name=meta["display"], temp_padding=meta["temp_padding"], features=True)
+        _, stats = o.predict(g["test"], g["ref"], dim_order=meta["dim_order"], frames_per_second=meta["fps"])
+        feats = stats["features"]
+        assert len(feats) == int(gf[f"case{k}_bands"])
+        for bb, f in enumerate(feats):
+            want = gf[f"case{k}_band{bb}"]
+            assert f.shape == want.shape, (bb, f.shape, want.shape)
+            for q in (0, 2, 4):
+                np.testing.assert_allclose(f[..., q], want[..., q], rtol=2e-5, atol=2e-7, err_msg=f"band {bb} mean {q}")
+                scale = np.abs(want[..., q]) ** 2 + np.abs(want[..., q + 1])
+                assert np.all(np.abs(f[..., q + 1] - want[..., q + 1]) <= 1e-4 * scale + 1e-8), f"band {bb} var {q + 1}"
+        k += 1
+    assert k == 2

@@ -45,6 +45,7 @@ struct cvvdp_handle {
   float eotf_tab[256];          // per-code display model of 8-bit sources (eotf_table), made once in cvvdp_create
   bool eotf_tab_ok = false;
   bool prof = false;
+  int fuse_levels = 0;          // leading pyramid levels whose band kernel computes the next level itself (k_band4f): no reduce pass for them
   std::vector<ProfEvent> events;
   size_t events_used = 0;
   // two-stage software pipeline over blocks (video, no heat map): FIR + reduce of block k+1 run on the
@@ -139,14 +140,22 @@ void heat_weights(const cvvdp_handle* h, bool baseband, float* w) {
   }
 }
 
-int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStream_t s);
+// levels [l_begin, L-1) + baseband + heat-map reconstruction; fused: only levels [l_begin, l_end) on k_band4f (each writes the next level)
+int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStream_t s, int l_begin = 0, int l_end = -1, bool fused = false);
 
 int run_pyramid_and_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, hipStream_t s) {
   const int B = h->c.batch, items = n_frames * B, L = h->L, nch = h->nch;
   const float K[5] = {0.25f - 0.4f / 2.0f, 0.25f, 0.4f, 0.25f, 0.25f - 0.4f / 2.0f};  // lpyr_dec.py:179
   const int set = h->pipeline ? h->cur_set : 0;
   static const bool fuse2 = dev_knob("CVVDP_REDUCE2", 1) != 0;
-  for (int l = 0; l + 1 < L; ++l) {
+  // The first fuse_levels levels need no reduce pass: their band kernels compute the next level from the rows they stream
+  // (band4f.hip) -- first those, in order (level l+1 is level l's by-product), then the reduce chain from the first level that
+  // is left, then the remaining bands.
+  const int F = h->pipeline ? 0 : h->fuse_levels;
+  if (F > 0) {
+    if (int e = run_bands(h, n_frames, q_frame_offset, 0, s, 0, F, true)) return e;
+  }
+  for (int l = F; l + 1 < L; ++l) {
     ProfScope ps(h, CVVDP_PROF_REDUCE, s);
     if (fuse2 && l + 2 < L && reduce2_supported(h->lv[l].H, h->lv[l].W)) {   // two levels per pass
       Reduce2Args r{};
@@ -167,7 +176,7 @@ int run_pyramid_and_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, hip
     launch_reduce(r, s);
   }
   if (int e = check_launch(h, "reduce")) return e;
-  if (!h->pipeline) return run_bands(h, n_frames, q_frame_offset, 0, s);
+  if (!h->pipeline) return run_bands(h, n_frames, q_frame_offset, 0, s, F);
   // hand the pyramid set to the band stage on the internal stream; the caller's stream is free to start
   // the next block's FIR + reduce into the other set
   if (int e = ensure_pipeline_objects(h)) return e;
@@ -180,8 +189,9 @@ int run_pyramid_and_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, hip
   return CVVDP_OK;
 }
 
-int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStream_t s) {
+int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStream_t s, int l_begin, int l_end, bool fused) {
   const int B = h->c.batch, items = n_frames * B, L = h->L, nch = h->nch;
+  if (l_end < 0) l_end = L - 1;
   const float K[5] = {0.25f - 0.4f / 2.0f, 0.25f, 0.4f, 0.25f, 0.25f - 0.4f / 2.0f};  // lpyr_dec.py:179
   const bool heat = h->c.heatmap != CVVDP_HEATMAP_NONE;
   // Images and blocks of small frames: not even level 0 is a GPU-full of workgroups (768 resident; a 4K image has 752, then 192,
@@ -192,7 +202,7 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
   // keep the single stream: measured on 4K x 64, the overlap gains 0.1 ms of 19 and only makes the per-kernel timings overlap.
   static const bool fork_env = dev_knob("CVVDP_BAND_STREAMS", 1) != 0;
   static const int fork_max = dev_knob("CVVDP_BAND_STREAMS_MAX", 1024);
-  bool fork = fork_env && L >= 4 && (int64_t)items * h->lv[0].n_strip * h->lv[0].n_seg <= fork_max;
+  bool fork = !fused && fork_env && L >= 4 && (int64_t)items * h->lv[0].n_strip * h->lv[0].n_seg <= fork_max;
   if (fork && !h->aux_stream[0]) {
     bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i)
@@ -205,7 +215,7 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
     for (int i = 0; i < 2; ++i) (void)hipStreamWaitEvent(h->aux_stream[i], h->ev_fork, 0);
   }
   hipStream_t const s_main = s;
-  for (int l = 0; l + 1 < L; ++l) {
+  for (int l = l_begin; l < l_end; ++l) {
     const Level& lv = h->lv[l];
     hipStream_t s = (fork && l >= 2) ? h->aux_stream[l & 1] : s_main;
     ProfScope ps(h, l == 0 ? CVVDP_PROF_BAND0 : CVVDP_PROF_BAND_REST, s);
@@ -246,7 +256,11 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
     a.ddump = (h->c.debug_dump || (h->c.feature_size > 0 && !lv.feat4)) ? h->ws + lv.dd_off : nullptr;
     a.fdump = (h->c.feature_size > 0 && !lv.feat4) ? h->ws + lv.fd_off : nullptr;
     a.fsum = lv.feat4 ? h->ws + lv.fs_off : nullptr; a.fs = h->c.feature_size; a.f_pieces = lv.f_pieces;
-    if (lv.vec4) {
+    if (fused) {
+      a.g1_out = gbase(h, l + 1, set);
+      for (int i = 0; i < 5; ++i) a.rk[i] = K[i];
+      launch_band4f(a, s);
+    } else if (lv.vec4) {
       // W % 8 != 0: the edge strips are a small launch (n_seg * items workgroups) of a slower instantiation; in the same stream it
       // would cost a whole extra round of the row march, on its own stream it fills the GPU together with the aligned strips.
       // (Not while profiling: the per-kernel events sit on one stream.)
@@ -278,6 +292,7 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
     launch_finalize(f, s);
   }
   if (int e = check_launch(h, "band")) return e;
+  if (fused) return CVVDP_OK;       // (the caller goes on with the reduce chain and the remaining levels)
   {
     const Level& lv = h->lv[L - 1];
     hipStream_t s = fork ? h->aux_stream[(L - 1) & 1] : s_main;
@@ -383,6 +398,7 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
   }
   if (c.heatmap != CVVDP_HEATMAP_NONE && c.batch != 1) return fail(h, CVVDP_E_UNSUPPORTED, "heat maps need batch == 1");
   if (c.feature_size < 0) return fail(h, CVVDP_E_ARG, "feature_size must be >= 0");
+  if (c.fuse_mode < 0 || c.fuse_mode > 2) return fail(h, CVVDP_E_ARG, "fuse_mode must be 0, 1 or 2");
   h->c = c;
   h->nch = c.is_video ? 4 : 3;
   h->L = c.n_levels;
@@ -430,6 +446,23 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     H = (H + 1) / 2; W = (W + 1) / 2;
   }
   if (pad != 0 && pad != 6) return fail(h, CVVDP_E_UNSUPPORTED, "blur radius %d unsupported", pad);
+  // Levels whose band kernel computes the next level itself (band4f.hip: the level's planes are then read once, not twice, and
+  // the HBM-bound reduce pass of the level disappears: 4K x 64 fp32 18.4 -> 15.7 ms).  The plain scoring path only (no heat map,
+  // dump or features), aligned levels, and only clips whose blocks fill the GPU several times over -- images and small frames
+  // keep the independent levels that run side by side on three streams.  Decided per clip from the nominal block, like the
+  // segments and the edge-strip split: the same kernels score a frame whatever the block size.
+  h->fuse_levels = 0;
+  {
+    const int clip_frames = c.total_frames > 0 ? c.total_frames : 64;
+    const int nominal = c.is_video ? std::min(64, clip_frames) : 1;
+    static const int fuse_max = dev_knob("CVVDP_FUSE_LEVELS", CVVDP_MAX_LEVELS);
+    const bool plain = c.is_video && c.heatmap == CVVDP_HEATMAP_NONE && !c.debug_dump && c.feature_size <= 0;   // (k_band4f is instantiated for 4 channels)
+    const bool big = (int64_t)nominal * c.batch * h->lv[0].n_strip * h->lv[0].n_seg > 1024;
+    if (plain && c.fuse_mode != 2 && (big || c.fuse_mode == 1))
+      while (h->fuse_levels < fuse_max && h->fuse_levels + 1 < h->L && h->lv[h->fuse_levels].vec4 &&
+             band4f_supported(h->lv[h->fuse_levels].H, h->lv[h->fuse_levels].W))
+        ++h->fuse_levels;
+  }
   // ---- workspace plan (float offsets)
   size_t off = 0;
   const size_t P0 = (size_t)h->lv[0].P;

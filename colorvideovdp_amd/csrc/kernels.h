@@ -172,6 +172,9 @@ struct BandArgs {
   // [items][nch][f_pieces][6][W] (piece = cell row + segment index; f_pieces = ceil(H / fs) + n_seg), or null
   float* fsum;
   int32_t fs, f_pieces;
+  // k_band4f (band4f.hip): the level's reduce fused in -- level l+1 planes [2*nch][items_cap][Hc*Wc] written by the band kernel, reduce taps
+  float* g1_out;
+  float rk[5];
 };
 void launch_band(const BandArgs& a, bool blur, hipStream_t s);
 // vectorised variant: any W >= 16, blur on, seg_h even.  W % 8 != 0: every strip on the RAGGED instantiation, or (split_edge) the
@@ -180,6 +183,10 @@ void launch_band(const BandArgs& a, bool blur, hipStream_t s);
 // s_edge == s: one after the other)
 void launch_band4(const BandArgs& a, bool split_edge, hipStream_t s, hipStream_t s_edge);
 int band4_edge_strips(int W, int n_strip);   // how many trailing strips the RAGGED instantiation takes (0 when W % 8 == 0)
+// k_band4 with the level's 5x5 reduce fused in: computes level l+1 from the rows it streams and writes it to a.g1_out instead of
+// reading a.gc (which may be the same buffer).  W % 8 == 0, no heat map / dump / features.
+bool band4f_supported(int H, int W);
+void launch_band4f(const BandArgs& a, hipStream_t s);
 constexpr int kBand4StripWidth = 240;
 
 struct BaseArgs {

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CVVDP_ABI_VERSION 9
+#define CVVDP_ABI_VERSION 10
 #define CVVDP_MAX_FILTER_LEN 65 /* 0.25 s at up to 256 fps, cvvdp_metric.py:1059 */
 #define CVVDP_MAX_LEVELS 16
 #define CVVDP_MAX_WINDOW 256    /* filter_len - 1 + frames per block */
@@ -113,7 +113,10 @@ typedef struct cvvdp_clip {
                                    the same for every block and shard of a clip, so results stay bit-identical */
   int32_t feature_size;         /* > 0: also keep |T'|, |R'| and D of every band for cvvdp_get_features, pooled over
                                    feature_size x feature_size cells (ceil(pix_per_deg), cvvdp_ml_metric.py:351-355); 0: off */
-  int32_t reserved0;
+  int32_t fuse_mode;            /* 0 (normal use): the core decides per clip which pyramid levels run the band kernel that computes the
+                                   next level itself (no reduce pass for them; clips whose blocks fill the GPU several times over);
+                                   1: every level that supports it, whatever the size of the clip; 2: none.  1 / 2 are test hooks: the
+                                   two routes agree to rounding, not bit for bit */
   float taps[4 * CVVDP_MAX_FILTER_LEN];                             /* F[c][k], not flipped */
   float csf_rows[CVVDP_MAX_LEVELS * 4 * CVVDP_CSF_NODES];           /* [band][ch][node] log10 S */
 } cvvdp_clip;

@@ -144,6 +144,14 @@ void launch_band4(const BandArgs& a, bool split_edge, hipStream_t s, hipStream_t
   if (split_edge) { const int n = band4_edge_strips(a.W, a.n_strip); REQUIRE(n > 0 && n < a.n_strip, "k_band4: split with %d edge strips of %d", n, a.n_strip); }
   else REQUIRE(s == s_edge, "k_band4: side stream without a split");
 }
+bool band4f_supported(int H, int W) { return (W & 7) == 0 && W >= 32 && H >= 32; }   // (mirror of band4f.hip)
+void launch_band4f(const BandArgs& a, hipStream_t) {
+  chk_band(a, kBand4StripWidth, "k_band4f");
+  REQUIRE(band4f_supported(a.H, a.W) && a.nch == 4 && a.seg_h % 2 == 0 && a.seg_h >= 8, "k_band4f on %dx%d, %d channels, seg_h %d", a.W, a.H, a.nch, a.seg_h);
+  REQUIRE(!a.dchr && !a.ddump && !a.fdump && !a.fsum, "k_band4f with a heat map / dump / features buffer");
+  in_ws(a.g1_out, 2 * (size_t)a.nch * a.items_cap * a.Hc * a.Wc, "k_band4f level l+1 planes");
+  REQUIRE(a.g1_out == a.gc, "k_band4f writes another buffer than the next level's planes");
+}
 void launch_baseband(const BaseArgs& a, hipStream_t) {
   ++g_launches;
   const size_t P = (size_t)a.H * a.W;
@@ -242,6 +250,7 @@ int main(int argc, char** argv) {
       c.debug_dump = ri(0, 9) == 0;
       c.raw_halo = ri(0, 1);
       c.feature_size = (c.heatmap == 0 && ri(0, 3) == 0) ? ri(1, 90) : 0;
+      c.fuse_mode = ri(0, 5) == 0 ? ri(0, 3) : 0;                                        // 3: out of range, must be refused
       for (int i = 0; i < 4 * CVVDP_MAX_FILTER_LEN; ++i) c.taps[i] = 0.01f * (i % 7);
       for (auto& v : c.csf_rows) v = 1.0f;
       snprintf(g_case, sizeof g_case, "#%d %dx%d B%d C%d video %d fl %d frames %d/%d block %d levels %d heat %d dump %d halo %d fs %d eotf %d", k, c.width,

@@ -789,3 +789,66 @@ def test_fused_features_on_ragged_multi_strip_frames(W, H, F, disp):
             np.testing.assert_allclose(got[..., q], want[..., q], rtol=5e-4, atol=2e-6, err_msg=f"band {bb} mean {q}")
             scale = np.abs(want[..., q]) ** 2 + np.abs(want[..., q + 1])
             assert np.all(np.abs(got[..., q + 1] - want[..., q + 1]) <= 2e-3 * scale + 1e-7), f"band {bb} var {q + 1}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# k_band4f (band4f.hip): band kernels that compute the next pyramid level themselves.  Normal use picks them per clip for blocks that
+# fill the GPU several times over (the bench clips: test_bench_clip_against_reference holds them to the real reference); here the
+# test hook cvvdp.fuse_mode forces them on small frames, where the oracle is affordable and every border rule is close by.
+def _fuse_clip(W, H, F, seed):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:H, 0:W]
+    ref = np.stack([np.stack([0.45 + 0.3 * np.sin(2 * np.pi * (3.1 * x / W + f / 9.0) + c) * np.cos(2 * np.pi * 2.3 * y / H) for c in range(3)])
+                    for f in range(F)], axis=1)[None]
+    test = np.clip(ref + 0.05 * rng.standard_normal(ref.shape), 0, 1)
+    return np.round(test * 255).astype(np.uint8), np.round(ref * 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("W,H,F,fps,disp", [
+    (256, 144, 5, 30, "standard_fhd"),        # one strip, levels 256x144 -> 128x72 -> 64x36 fused
+    (736, 416, 3, 60, "standard_4k"),         # four strips (the last one narrow), several segments
+    (512, 271, 4, 24, "standard_fhd"),        # odd height: the last coarse row's extra taps, the row-parity column edge (Q1)
+    (1200, 90, 3, 50, "standard_4k"),         # W a multiple of the strip width, few rows: top and bottom mirrors in one segment
+    (248, 600, 3, 60, "standard_hdr_pq"),     # a strip whose 256 columns end exactly at the image; tall
+    (152, 69, 12, 30, "standard_fhd"),        # segments of 14 rows: shorter than two blur radii, the last one 13 rows
+])
+def test_fused_reduce_band_kernels(W, H, F, fps, disp):
+    import colorvideovdp_amd as cv
+    from colorvideovdp_amd import _capi
+    from oracle import cvvdp_oracle as orc
+    t, r = _fuse_clip(W, H, F, W + H)
+    ojod, ostats = orc.Oracle(display_name=disp).predict(t, r, dim_order="BCFHW", frames_per_second=fps)
+    runs = {}
+    for mode in (1, 2):
+        m = cv.cvvdp(display_name=disp)
+        m.fuse_mode = mode
+        jod, stats = m.predict(t, r, dim_order="BCFHW", frames_per_second=fps)
+        L = stats["Q_per_ch"].shape[-1]
+        pyr = []
+        hh, ww = H, W
+        for l in range(L):
+            pyr.append(m.debug_buffer(_capi.BUF_GPYR, l)[:8 * F * hh * ww].view(8, F, hh, ww).cpu().numpy().copy())
+            hh, ww = (hh + 1) // 2, (ww + 1) // 2
+        runs[mode] = (float(jod), stats["Q_per_ch"], pyr)
+    (j1, q1, p1), (j2, q2, p2) = runs[1], runs[2]
+    # the pyramid: levels written by the band kernels against the reduce kernels' (same taps, another summation order)
+    for l, (a, b) in enumerate(zip(p1, p2)):
+        np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-6 * max(1.0, float(np.abs(b).max())), err_msg=f"pyramid level {l}")
+    assert not np.array_equal(p1[1], p2[1]) or W * H < 0      # (the two routes do round differently: the fused one did run)
+    np.testing.assert_allclose(q1, q2, rtol=5e-5, atol=5e-7)
+    assert abs(j1 - float(ojod)) <= JOD_TOL and abs(j2 - float(ojod)) <= JOD_TOL
+    np.testing.assert_allclose(q1, ostats["Q_per_ch"], rtol=2e-4, atol=2e-6)
+
+
+def test_fused_route_is_a_property_of_the_clip():
+    """Blocks and shards of a clip take the same kernels (the decision uses the nominal block): bit-identical for any blocking."""
+    import colorvideovdp_amd as cv
+    t, r = _fuse_clip(736, 416, 9, 5)
+    qs = []
+    for nb in (None, 4, 1):
+        m = cv.cvvdp(display_name="standard_4k", block_frames=nb)
+        m.fuse_mode = 1
+        _, st = m.predict(t, r, dim_order="BCFHW", frames_per_second=60)
+        qs.append(st["Q_per_ch"])
+    np.testing.assert_array_equal(qs[0], qs[1])
+    np.testing.assert_array_equal(qs[0], qs[2])

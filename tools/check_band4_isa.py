@@ -69,7 +69,7 @@ def check_kernel(name, lines):
     for lo, hi in loops:
         body = lines[lo:hi + 1]
         # streaming loops = loops that contain a hand-issued load (inline asm shows up between ;;#ASMSTART / ;;#ASMEND)
-        if not any("global_load_dwordx4" in l and "ASMSTART" in body[i - 1] for i, l in enumerate(body) if i > 0):
+        if not any("global_load_dword" in l and "ASMSTART" in body[i - 1] for i, l in enumerate(body) if i > 0):
             continue
         b, n = _walk(name, body, 2, f"loop at line {lo}")      # twice around: covers the back edge
         bad += b
@@ -83,17 +83,26 @@ def check_kernel(name, lines):
     return bad, n_loads, len(loops)
 
 
-def main(path):
+def main(paths):
+    total_bad = 0
+    for path in paths:
+        total_bad += check_file(path)
+    return 1 if total_bad else 0
+
+
+def check_file(path):
     text = open(path).read().split("\n")
-    starts = [i for i, l in enumerate(text) if re.match(r"^_ZN5cvvdp7k_band4.*:\s*(;.*)?$", l)]
+    starts = [i for i, l in enumerate(text) if re.match(r"^_ZN5cvvdp\d+k_band4f?I.*:\s*(;.*)?$", l)]
     total_bad = 0
     for s in starts:
         e = next(i for i in range(s, len(text)) if ".end_amdhsa_kernel" in text[i] or text[i].startswith("\t.section"))
         bad, n_loads, n_loops = check_kernel(text[s].split(":")[0], text[s:e])
         print(f"{text[s].split(':')[0]}: {n_loops} loops, {n_loads} loads in streaming loops, {bad} violations")
+        assert n_loads > 0, f"{text[s].split(':')[0]}: no hand-issued loads found (checker out of date?)"
         total_bad += bad
-    return 1 if total_bad else 0
+    assert starts, f"{path}: no k_band4 / k_band4f kernels found"
+    return total_bad
 
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv[1] if len(sys.argv) > 1 else "/tmp/isa/band4_new.s"))
+    sys.exit(main(sys.argv[1:] if len(sys.argv) > 1 else ["/tmp/isa/band4_new.s"]))

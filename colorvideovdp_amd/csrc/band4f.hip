@@ -53,7 +53,10 @@ __device__ __forceinline__ void f_lds_write4(float* p, const float (&v)[4]) {
 
 }  // namespace
 
-template <int NCH>
+// EDGE: the launch holds the strips that touch the left or right image border (strip 0 and the last one or two); the other strips run
+// the instantiation without any of the border code (zero masks, first / last column taps, replicas, blur mirrors), as a second
+// launch beside it.
+template <int NCH, bool EDGE>
 __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   constexpr int NP = 2 * NCH;
   __shared__ __attribute__((aligned(16))) float2 s_ve[2][NP][F_VE / 2];
@@ -69,14 +72,16 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   const int j = t & 63;
   const int per_xcd = a.per_xcd;
   const int wu = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);      // XCD-aware work-unit order (band4.hip)
-  if (wu >= a.n_strip * a.n_seg * a.items) return;
-  const int strip = wu % a.n_strip, seg = (wu / a.n_strip) % a.n_seg, item = wu / (a.n_strip * a.n_seg);
+  if (wu >= a.n_strip_l * a.n_seg * a.items) return;
+  const int sl = wu % a.n_strip_l, seg = (wu / a.n_strip_l) % a.n_seg, item = wu / (a.n_strip_l * a.n_seg);
+  // EDGE launch: strip 0 and the last n_strip_l - 1 strips; the other launch: strips strip0 .. strip0 + n_strip_l - 1
+  const int strip = EDGE ? (sl == 0 ? 0 : a.n_strip - a.n_strip_l + sl) : a.strip0 + sl;
   const int H = a.H, W = a.W, Hc = a.Hc, Wc = a.Wc;
   const int x0 = strip * F_SW;
   const int fc0 = x0 - F_HALO + 4 * j;
   const bool in_img = fc0 >= 0 && fc0 < W;
   const bool edge_r = x0 + F_SW + F_HALO > W;
-  const bool edge_lr = strip == 0 || edge_r;        // block-uniform: the strip touches the left or right image border
+  constexpr bool edge_lr = EDGE;                    // (launch_band4f deals the strips accordingly)
   const bool interior = j >= 2 && j < 62 && fc0 < W;
   const int cb = (x0 - F_HALO) / 2;
   const int ys = seg * a.seg_h, ye = min(H, ys + a.seg_h);
@@ -116,16 +121,10 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   const uint32_t goff = (uint32_t)min(max(fc0, 0), W - 4) * 4u;                       // own four columns
   const uint32_t loff = (uint32_t)min(max(fc0 - 2, 0), W - 2) * 4u;                   // columns fc0-2, fc0-1
   const uint32_t roff = (uint32_t)min(max(fc0 + 4, 0), W - 1) * 4u;                   // column fc0+4
-  const float mV = in_img ? 1.0f : 0.0f;
-  const float mL = (fc0 - 2 >= 0 && fc0 - 2 < W) ? 1.0f : 0.0f;
-  const float mR = (fc0 + 4 >= 0 && fc0 + 4 < W) ? 1.0f : 0.0f;
-  // first / last output column (lpyr_dec.py:205-209; the last column's extra taps depend on the ROW parity, sic)
-  const float wl1 = fc0 == 0 ? rk1 : 0.0f, wl0 = fc0 == 0 ? rk0 : 0.0f;
-  const float wr3 = fc0 == W - 4 ? ((H & 1) ? rk3 : rk4) : 0.0f, wr2 = (fc0 == W - 4 && (H & 1)) ? rk4 : 0.0f;
-  // coarse columns left of column 0 / right of column Wc-1 are its replicas in the expand (lpyr_dec.py:223-239 clamps)
+  // (the zero masks and the first / last column's extra taps are made from fc0 inside the edge_lr branches: nothing of them is live in
+  // the strips away from the image border)
   const int lane_first = 2;                                       // strip 0: the lane of fine column 0
   const int lane_last = (W - 4 - (x0 - F_HALO)) >> 2;             // the lane of fine columns W-4 .. W-1 (edge_r strips: 0 .. 63)
-  const bool rep_left = fc0 < 0, rep_right = fc0 >= W;
 
   float4 cA = make_float4(0, 0, 0, 0), cB = cA, cC = cA;          // coarse rows my-1, my, my+1 of this lane's two coarse columns: (T0, T1, R0, R1)
   float4 rP = cA, rQ = cA;                                        // partial sums of the two coarse rows under construction (older, younger)
@@ -149,7 +148,10 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   // One level-l row (four own samples + three neighbours per plane) through the horizontal pass, then into the running sums.
   // a_row: its index (scalar).  Returns true and the completed coarse row (a_row/2 - 1) on even rows.
   auto consume = [&](int a_row, auto odd_a, v4f vT, v4f vR, v2f lT, float rT, v2f lR, float rR, float4& emitted) {
-    if (edge_lr) {
+    if constexpr (edge_lr) {
+      const float mV = in_img ? 1.0f : 0.0f;
+      const float mL = (fc0 - 2 >= 0 && fc0 - 2 < W) ? 1.0f : 0.0f;
+      const float mR = (fc0 + 4 >= 0 && fc0 + 4 < W) ? 1.0f : 0.0f;
       vT *= mV; vR *= mV; lT *= mL; lR *= mL; rT *= mR; rR *= mR;
     }
     float4 hr;
@@ -157,33 +159,48 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
     hr.y = __builtin_fmaf(rT, rk4, __builtin_fmaf(vT.w, rk3, __builtin_fmaf(vT.z, rk2, __builtin_fmaf(vT.y, rk1, vT.x * rk0))));
     hr.z = __builtin_fmaf(vR.z, rk4, __builtin_fmaf(vR.y, rk3, __builtin_fmaf(vR.x, rk2, __builtin_fmaf(lR.y, rk1, lR.x * rk0))));
     hr.w = __builtin_fmaf(rR, rk4, __builtin_fmaf(vR.w, rk3, __builtin_fmaf(vR.z, rk2, __builtin_fmaf(vR.y, rk1, vR.x * rk0))));
-    if (edge_lr) {
+    if constexpr (edge_lr) {
+      // first / last output column (lpyr_dec.py:205-209; the last column's extra taps depend on the ROW parity, sic)
+      const float wl1 = fc0 == 0 ? rk1 : 0.0f, wl0 = fc0 == 0 ? rk0 : 0.0f;
+      const float wr3 = fc0 == W - 4 ? ((H & 1) ? rk3 : rk4) : 0.0f, wr2 = (fc0 == W - 4 && (H & 1)) ? rk4 : 0.0f;
       hr.x = __builtin_fmaf(vT.y, wl0, __builtin_fmaf(vT.x, wl1, hr.x));
       hr.z = __builtin_fmaf(vR.y, wl0, __builtin_fmaf(vR.x, wl1, hr.z));
       hr.y = __builtin_fmaf(vT.z, wr2, __builtin_fmaf(vT.w, wr3, hr.y));
       hr.w = __builtin_fmaf(vR.z, wr2, __builtin_fmaf(vR.w, wr3, hr.w));
     }
-    // vertical weights of this row (scalars): zero for rows outside the image, the first / last coarse row's extra taps folded in
+    // Vertical pass.  Rows outside the image are the zero padding (nothing to add); the first / last coarse row's extra taps
+    // (lpyr_dec.py:195-199) are added in uniform branches that only the image's first and last two rows take.
     const bool ok = a_row >= 0 && a_row < H;
+    const bool border = a_row <= 1 || a_row >= H - 2;               // (scalar)
+    auto axpy = [](float4& y, const float4& x, float w) {
+      y.x = __builtin_fmaf(x.x, w, y.x); y.y = __builtin_fmaf(x.y, w, y.y); y.z = __builtin_fmaf(x.z, w, y.z); y.w = __builtin_fmaf(x.w, w, y.w);
+    };
     if constexpr (decltype(odd_a)::value) {
-      float wP = rk3, wQ = rk1;
-      if (a_row == 1) wP += rk0;                                   // coarse row 0: + k0 * row 1              (lpyr_dec.py:195)
-      if (!(H & 1) && a_row == H - 1) wP += rk4;                   // H even, last coarse row: + k4 * row H-1  (:199)
-      if ((H & 1) && a_row == H - 2) wQ += rk4;                    // H odd,  last coarse row: + k4 * row H-2  (:196-197)
-      if (!ok) { wP = 0.0f; wQ = 0.0f; }
-      rP.x = __builtin_fmaf(hr.x, wP, rP.x); rP.y = __builtin_fmaf(hr.y, wP, rP.y); rP.z = __builtin_fmaf(hr.z, wP, rP.z); rP.w = __builtin_fmaf(hr.w, wP, rP.w);
-      rQ.x = __builtin_fmaf(hr.x, wQ, rQ.x); rQ.y = __builtin_fmaf(hr.y, wQ, rQ.y); rQ.z = __builtin_fmaf(hr.z, wQ, rQ.z); rQ.w = __builtin_fmaf(hr.w, wQ, rQ.w);
+      if (ok) {
+        axpy(rP, hr, rk3);
+        axpy(rQ, hr, rk1);
+        if (border) {
+          if (a_row == 1) axpy(rP, hr, rk0);                        // coarse row 0: + k0 * row 1
+          if (!(H & 1) && a_row == H - 1) axpy(rP, hr, rk4);        // H even, last coarse row: + k4 * row H-1
+          if ((H & 1) && a_row == H - 2) axpy(rQ, hr, rk4);         // H odd,  last coarse row: + k4 * row H-2
+        }
+      }
     } else {
-      float wP = rk4, wQ = rk2, wN = rk0;
-      if (a_row == 0) wQ += rk1;                                   // coarse row 0: + k1 * row 0
-      if ((H & 1) && a_row == H - 1) wQ += rk3;                    // H odd, last coarse row: + k3 * row H-1
-      if (!ok) { wP = 0.0f; wQ = 0.0f; wN = 0.0f; }
-      emitted = make_float4(__builtin_fmaf(hr.x, wP, rP.x), __builtin_fmaf(hr.y, wP, rP.y), __builtin_fmaf(hr.z, wP, rP.z), __builtin_fmaf(hr.w, wP, rP.w));
-      rP = make_float4(__builtin_fmaf(hr.x, wQ, rQ.x), __builtin_fmaf(hr.y, wQ, rQ.y), __builtin_fmaf(hr.z, wQ, rQ.z), __builtin_fmaf(hr.w, wQ, rQ.w));
-      rQ = make_float4(hr.x * wN, hr.y * wN, hr.z * wN, hr.w * wN);
+      if (ok) {
+        axpy(rP, hr, rk4);
+        axpy(rQ, hr, rk2);
+        if (border) {
+          if (a_row == 0) axpy(rQ, hr, rk1);                        // coarse row 0: + k1 * row 0
+          if ((H & 1) && a_row == H - 1) axpy(rQ, hr, rk3);         // H odd, last coarse row: + k3 * row H-1
+        }
+      }
+      emitted = rP;
+      rP = rQ;
+      rQ = ok ? make_float4(hr.x * rk0, hr.y * rk0, hr.z * rk0, hr.w * rk0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       const int m1 = (a_row >> 1) - 1;                             // the coarse row just completed
       if (m1 > Hc - 1) emitted = cC;                               // below the last coarse row: its replica (the expand clamps)
-      if (edge_lr) {                                               // coarse columns outside the image: replicas of column 0 / Wc-1
+      if constexpr (edge_lr) {                                     // coarse columns outside the image: replicas of column 0 / Wc-1
+        const bool rep_left = fc0 < 0, rep_right = fc0 >= W;
         if (strip == 0) {
           const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, emitted.x), lane_first));
           const float r0_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, emitted.z), lane_first));
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   auto rowc = [&](int r) { return min(max(r, 0), H - 1); };       // rows outside the image: any valid row (their weight is 0)
 
   // image-edge mirror roles of the contrast stage (band4.hip): reflect padding of the blur at the left / right image border
-  const bool mir_block = strip == 0 || edge_r;
+  const bool mir_block = EDGE && (strip == 0 || edge_r);
   int mir_kind = 0, mir_base = 0;
   if (strip == 0 && (fc0 == 0 || fc0 == 4)) { mir_kind = fc0 == 0 ? 1 : 2; mir_base = F_HALO - (fc0 == 0 ? 1 : 4); }
   if (fc0 == W - 8 || fc0 == W - 4) {
@@ -521,12 +538,24 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
 
 bool band4f_supported(int H, int W) { return (W & 7) == 0 && W >= 32 && H >= 32; }
 
-void launch_band4f(const BandArgs& a0, hipStream_t s) {
+// strips whose 256 columns x0-8 .. x0+247 reach past the right image border (trailing; at least the last one)
+static int band4f_right_edge_strips(int W, int n_strip) {
+  int n = 0;
+  while (n < n_strip && (n_strip - 1 - n) * F_SW + F_SW + F_HALO > W) ++n;
+  return n;
+}
+
+void launch_band4f(const BandArgs& a0, hipStream_t s, hipStream_t s_edge) {
   BandArgs a = a0;
-  a.strip0 = 0; a.n_strip_l = a.n_strip;
-  a.per_xcd = (a.n_strip * a.n_seg * a.items + 7) / 8;
-  dim3 grid(8 * a.per_xcd);
-  hipLaunchKernelGGL((k_band4f<4>), grid, dim3(256), 0, s, a);     // video only (core.cpp): image batches keep k_band4 + the reduce pass
+  const int n_edge = std::min(a.n_strip, 1 + band4f_right_edge_strips(a.W, a.n_strip));   // strip 0 + the right-edge strips
+  a.strip0 = 0; a.n_strip_l = n_edge;
+  a.per_xcd = (a.n_strip_l * a.n_seg * a.items + 7) / 8;
+  hipLaunchKernelGGL((k_band4f<4, true>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);     // video only (core.cpp)
+  if (n_edge < a.n_strip) {
+    a.strip0 = 1; a.n_strip_l = a.n_strip - n_edge;
+    a.per_xcd = (a.n_strip_l * a.n_seg * a.items + 7) / 8;
+    hipLaunchKernelGGL((k_band4f<4, false>), dim3(8 * a.per_xcd), dim3(256), 0, s, a);
+  }
 }
 
 }  // namespace cvvdp

@@ -256,33 +256,35 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
     a.ddump = (h->c.debug_dump || (h->c.feature_size > 0 && !lv.feat4)) ? h->ws + lv.dd_off : nullptr;
     a.fdump = (h->c.feature_size > 0 && !lv.feat4) ? h->ws + lv.fd_off : nullptr;
     a.fsum = lv.feat4 ? h->ws + lv.fs_off : nullptr; a.fs = h->c.feature_size; a.f_pieces = lv.f_pieces;
+    // Levels whose strips at the image border run as their own launch (k_band4 on ragged frames: split_edge; k_band4f: always): a
+    // small launch of a slower instantiation.  In the same stream it would cost a whole extra round of the row march; on its own
+    // stream -- ordered after everything that precedes this level on s, joined before the finish kernel reads the partial sums
+    // (and before the next level reads what this one wrote) -- it fills the GPU together with the other strips.  The profiling
+    // events of the level sit on s before the fork and after the join: they time the pair of launches.
+    hipStream_t s_edge = s;
+    if (fused || (lv.vec4 && lv.split_edge)) {
+      if (!h->edge_stream) {
+        if (hipStreamCreateWithFlags(&h->edge_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_edge_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_edge_join, hipEventDisableTiming) != hipSuccess)
+          return fail(h, CVVDP_E_HIP, "cannot create the edge-strip stream of the band stage");
+      }
+      s_edge = h->edge_stream;
+      (void)hipEventRecord(h->ev_edge_fork, s);
+      (void)hipStreamWaitEvent(s_edge, h->ev_edge_fork, 0);
+    }
     if (fused) {
       a.g1_out = gbase(h, l + 1, set);
       for (int i = 0; i < 5; ++i) a.rk[i] = K[i];
-      launch_band4f(a, s);
+      launch_band4f(a, s, s_edge);
     } else if (lv.vec4) {
-      // W % 8 != 0: the edge strips are a small launch (n_seg * items workgroups) of a slower instantiation; in the same stream it
-      // would cost a whole extra round of the row march, on its own stream it fills the GPU together with the aligned strips.
-      // (Not while profiling: the per-kernel events sit on one stream.)
-      hipStream_t s_edge = s;
-      if (lv.split_edge && !h->prof) {
-        if (!h->edge_stream) {
-          if (hipStreamCreateWithFlags(&h->edge_stream, hipStreamNonBlocking) != hipSuccess ||
-              hipEventCreateWithFlags(&h->ev_edge_fork, hipEventDisableTiming) != hipSuccess ||
-              hipEventCreateWithFlags(&h->ev_edge_join, hipEventDisableTiming) != hipSuccess)
-            return fail(h, CVVDP_E_HIP, "cannot create the edge-strip stream of the band stage");
-        }
-        s_edge = h->edge_stream;
-        (void)hipEventRecord(h->ev_edge_fork, s);                   // after the pyramid (and whatever else precedes this level on s)
-        (void)hipStreamWaitEvent(s_edge, h->ev_edge_fork, 0);
-      }
       launch_band4(a, lv.split_edge, s, s_edge);
-      if (s_edge != s) {                                            // the finish kernel below reads the partial sums of both launches
-        (void)hipEventRecord(h->ev_edge_join, s_edge);
-        (void)hipStreamWaitEvent(s, h->ev_edge_join, 0);
-      }
     } else {
       launch_band(a, lv.blur, s);
+    }
+    if (s_edge != s) {
+      (void)hipEventRecord(h->ev_edge_join, s_edge);
+      (void)hipStreamWaitEvent(s, h->ev_edge_join, 0);
     }
     FinalizeArgs f{};
     f.partial = a.partial; f.items = items; f.nblk = lv.n_strip * lv.n_seg; f.nch = nch; f.P = (int)lv.P;

@@ -186,7 +186,8 @@ int band4_edge_strips(int W, int n_strip);   // how many trailing strips the RAG
 // k_band4 with the level's 5x5 reduce fused in: computes level l+1 from the rows it streams and writes it to a.g1_out instead of
 // reading a.gc (which may be the same buffer).  W % 8 == 0, no heat map / dump / features.
 bool band4f_supported(int H, int W);
-void launch_band4f(const BandArgs& a, hipStream_t s);
+// (the strips at the left / right image border as their own launch on s_edge -- a side stream ordered like launch_band4's, or s)
+void launch_band4f(const BandArgs& a, hipStream_t s, hipStream_t s_edge);
 constexpr int kBand4StripWidth = 240;
 
 struct BaseArgs {

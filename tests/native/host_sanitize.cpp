@@ -145,7 +145,7 @@ void launch_band4(const BandArgs& a, bool split_edge, hipStream_t s, hipStream_t
   else REQUIRE(s == s_edge, "k_band4: side stream without a split");
 }
 bool band4f_supported(int H, int W) { return (W & 7) == 0 && W >= 32 && H >= 32; }   // (mirror of band4f.hip)
-void launch_band4f(const BandArgs& a, hipStream_t) {
+void launch_band4f(const BandArgs& a, hipStream_t, hipStream_t) {
   chk_band(a, kBand4StripWidth, "k_band4f");
   REQUIRE(band4f_supported(a.H, a.W) && a.nch == 4 && a.seg_h % 2 == 0 && a.seg_h >= 8, "k_band4f on %dx%d, %d channels, seg_h %d", a.W, a.H, a.nch, a.seg_h);
   REQUIRE(!a.dchr && !a.ddump && !a.fdump && !a.fsum, "k_band4f with a heat map / dump / features buffer");

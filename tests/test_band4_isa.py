@@ -33,3 +33,24 @@ def test_no_instruction_touches_a_register_with_a_load_in_flight(tmp_path):
         # and the steady-state loop waits with the exact counts, not with a drain
         body = "\n".join(text[s:e])
         assert "s_waitcnt vmcnt(3)" in body and "s_waitcnt vmcnt(2)" in body
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
+def test_fused_kernel_streams_are_safe_too(tmp_path):
+    """k_band4f (band4f.hip) keeps six loads per row in flight across two barriers and an 8-row register ring; same check."""
+    asm = tmp_path / "band4f.s"
+    cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-x", "hip",
+           "--cuda-device-only", "-S", os.path.join(ROOT, "colorvideovdp_amd", "csrc", "band4f.hip"), "-o", str(asm)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    spec = importlib.util.spec_from_file_location("check_band4_isa", os.path.join(ROOT, "tools", "check_band4_isa.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    text = asm.read_text().split("\n")
+    starts = [i for i, l in enumerate(text) if l.startswith("_ZN5cvvdp8k_band4f") and l.rstrip().split(";")[0].rstrip().endswith(":")]
+    assert len(starts) == 2                                           # border strips / all other strips
+    for s in starts:
+        e = next(i for i in range(s, len(text)) if ".end_amdhsa_kernel" in text[i] or text[i].startswith("\t.section"))
+        bad, n_loads, n_loops = chk.check_kernel(text[s].split(":")[0], text[s:e])
+        assert n_loads == 48 and bad == 0, (n_loads, bad)          # eight steps x (four neighbour loads + two row loads)
+        assert "\n".join(text[s:e]).count("s_waitcnt vmcnt(2)") >= 8

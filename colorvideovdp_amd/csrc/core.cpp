@@ -460,9 +460,13 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     static const int fuse_max = dev_knob("CVVDP_FUSE_LEVELS", CVVDP_MAX_LEVELS);
     const bool plain = c.is_video && c.heatmap == CVVDP_HEATMAP_NONE && !c.debug_dump && c.feature_size <= 0;   // (k_band4f is instantiated for 4 channels)
     const bool big = (int64_t)nominal * c.batch * h->lv[0].n_strip * h->lv[0].n_seg > 1024;
+    // ... and level by level only while the level itself is large (>= 16 M pixels in the nominal block): on small levels the fused
+    // kernel's longer prologue and two-block occupancy cost more than the small reduce pass they replace (sweep over the number
+    // of fused levels, profiles/r03_dev_notes.txt: best at 3 levels for 4K x 64, 2 for 1080p x 64)
     if (plain && c.fuse_mode != 2 && (big || c.fuse_mode == 1))
       while (h->fuse_levels < fuse_max && h->fuse_levels + 1 < h->L && h->lv[h->fuse_levels].vec4 &&
-             band4f_supported(h->lv[h->fuse_levels].H, h->lv[h->fuse_levels].W))
+             band4f_supported(h->lv[h->fuse_levels].H, h->lv[h->fuse_levels].W) &&
+             (c.fuse_mode == 1 || (int64_t)h->lv[h->fuse_levels].P * nominal * c.batch >= (int64_t)1 << 24))
         ++h->fuse_levels;
   }
   // ---- workspace plan (float offsets)

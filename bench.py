@@ -45,11 +45,26 @@ WORKLOADS = {
 GOLDEN = {("4k64", "f32"): "bench_4k64_f32", ("fhd64", "f32"): "bench_fhd64_f32", ("4k256", "u8"): "bench_4k256_u8"}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
 # whole-path algorithmic bytes per pixel of the test clip.  "survey": SURVEY.md 8(d)'s model, which includes a DKL ring
-# (24 B written + 24 B read) that this design does not have; "build": what this build's kernels have to move --
-# FIR 24 in + 32 out, reduce 32*4/3 in + 32/3 out, band 32*4/3 + 32/3 in
+# (24 B written + 24 B read) that this design does not have and reads every pyramid level twice; "build": what this build's
+# kernels have to move (build_bytes_per_pixel below)
 PATH_BYTES_PER_PIXEL = {"f32": 211.0, "u8": 193.0, "yuv420p8": 190.0, "yuv420p10": 193.0}
-BUILD_BYTES_PER_PIXEL = {"f32": 24 + 32 + 53.3 + 53.3, "u8": 6 + 32 + 53.3 + 53.3, "yuv420p8": 3 + 32 + 53.3 + 53.3, "yuv420p10": 6 + 32 + 53.3 + 53.3}
-BAND0_BYTES_PER_PIXEL = 40.0   # level-0 band kernel: reads g0 (8 planes x 4 B) + g1 (8 x 4 / 4)
+INPUT_BYTES_PER_PIXEL = {"f32": 24.0, "u8": 6.0, "yuv420p8": 3.0, "yuv420p10": 6.0}
+BAND0_BYTES_PER_PIXEL = 40.0   # level-0 band kernel: g0 in (8 planes x 4 B) + g1 (8 x 4 / 4) in (k_band4) or OUT (k_band4f, which computes it)
+
+
+def stage_bytes_per_pixel(dtype, fused_levels):
+    """Algorithmic bytes per pixel of the test clip, per kernel family.  FIR: samples in + 8 level-0 planes out.  A level l (1/4^l
+    of the pixels, 32 B per pixel of the level) whose band kernel is fused (band4f.hip, the first `fused_levels` levels) is read once
+    and its next level written once by that kernel (40 / 4^l); from the first unfused level on, every level is read by a reduce pass
+    (32/4^l) that writes the next one (8/4^l), and read again with its coarse level by its band kernel (40/4^l)."""
+    F = max(int(fused_levels), 0)
+    tail = (4.0 / 3.0) / 4 ** F                      # sum over l >= F of 1/4^l
+    fused = sum(40.0 / 4 ** l for l in range(F))
+    b = {"temporal_fir": INPUT_BYTES_PER_PIXEL[dtype] + 32.0,
+         "pyr_reduce": 32.0 * tail + 32.0 * (tail - 1.0 / 4 ** F),
+         "band_level0": 40.0,
+         "band_rest": fused + 40.0 * tail - 40.0}
+    return b
 
 
 def code_stamp():
@@ -409,13 +424,18 @@ def main():
             out["reference_fixture"] = f"tests/golden/{GOLDEN[(args.workload, dtype)]}.npz (the real reference on this very clip, oracle/make_goldens_bench.py)"
         else:
             out["jod_delta_vs_reference"] = None      # this torch build's CPU generator does not reproduce the fixture's frames
-    surv, build = PATH_BYTES_PER_PIXEL[dtype], BUILD_BYTES_PER_PIXEL[dtype]
+    fused_levels = m.fused_levels
+    stage_b = stage_bytes_per_pixel(dtype, fused_levels)
+    surv, build = PATH_BYTES_PER_PIXEL[dtype], sum(stage_b.values())
+    out["config"]["fused_levels"] = fused_levels    # leading pyramid levels whose band kernel computes the next level itself (no reduce pass)
     out["path_roofline"] = {
         "survey_model": {"bytes_per_pixel": surv, "achieved_GBs": round(surv * pixels / dt / 1e9 / world, 1),
                          "frac_of_8TBs_per_gpu": round(surv * pixels / dt / 1e9 / world / HBM_PEAK_GBS, 4),
-                         "note": "SURVEY.md 8(d): includes a 48 B/pixel DKL ring this design does not have"},
+                         "note": "SURVEY.md 8(d): includes a 48 B/pixel DKL ring this design does not have and reads every level twice"},
         "build_algorithmic": {"bytes_per_pixel": round(build, 1), "achieved_GBs": round(build * pixels / dt / 1e9 / world, 1),
-                              "frac_of_8TBs_per_gpu": round(build * pixels / dt / 1e9 / world / HBM_PEAK_GBS, 4)},
+                              "frac_of_8TBs_per_gpu": round(build * pixels / dt / 1e9 / world / HBM_PEAK_GBS, 4),
+                              "note": "fewer algorithmic bytes than round 2 (162.6 for f32): fused band kernels read a level once, so the "
+                                      "same pixel rate is a smaller fraction" if fused_levels > 0 else "no fused levels for this clip"},
     }
     if prof is not None:
         ms, n = prof["band_level0"]
@@ -441,18 +461,20 @@ def main():
                 traffic = (ktraffic or {}).get("band_level0", {}).get("hbm_bytes_per_launch")
                 traffic_note = ("FETCH_SIZE x 2 + WRITE_SIZE per launch from separate --pmc passes over these kernel sources (stamp matches; "
                                 f"library binary {'identical' if have.get('lib_sha256') == stamp['lib_sha256'] else 'rebuilt from the same sources'})")
-        out["roofline"] = {"bound": "hbm", "kernel": "k_band4<4> level 0 (fused expand/contrast/CSF/masking/blur/pooling)",
+        out["roofline"] = {"bound": "hbm", "kernel": ("k_band4f<4> level 0 (5x5 reduce to level 1 + expand/contrast/CSF/masking/blur/pooling; border strips as a "
+                                                      "second launch beside the others: the pair is timed)") if fused_levels > 0 else
+                                                     "k_band4<4> level 0 (fused expand/contrast/CSF/masking/blur/pooling)",
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "traffic_note": traffic_note, "avg_launch_ms": round(avg_ms, 4), "launches": n,
                            "algorithmic_bytes_per_launch": BAND0_BYTES_PER_PIXEL * W * H * frames_per_launch}
         # the other two dominant kernels on the same footing (algorithmic bytes per step / HIP-event time per step / 8 TB/s)
         px_step = W * H * count
-        in_b = {"f32": 24.0, "u8": 6.0, "yuv420p8": 3.0, "yuv420p10": 6.0}[dtype]
+        in_b = INPUT_BYTES_PER_PIXEL[dtype]
         out["kernel_roofline"] = {}
-        for key, bpp, what in (("temporal_fir", in_b + 32.0, f"{in_b:g} B/pixel in + 32 out (8 level-0 planes)"),
-                               ("pyr_reduce", 32.0 * 4 / 3 + 32.0 / 3, "every level read once (32*4/3 B/pixel), levels 1.. written once (32/3)"),
-                               ("band_level0", BAND0_BYTES_PER_PIXEL, "g0 32 + g1 8 B/pixel in"),
-                               ("band_rest", 40.0 / 3, "levels 1..: (32 + 8)/3 B/pixel in")):
+        for key, bpp, what in (("temporal_fir", stage_b["temporal_fir"], f"{in_b:g} B/pixel in + 32 out (8 level-0 planes)"),
+                               ("pyr_reduce", stage_b["pyr_reduce"], f"levels {fused_levels}.. read once, levels {fused_levels + 1}.. written once (the fused levels have no reduce pass)"),
+                               ("band_level0", stage_b["band_level0"], "g0 32 B/pixel in + g1 8 " + ("out" if fused_levels > 0 else "in")),
+                               ("band_rest", stage_b["band_rest"], "levels 1..: (32 + 8)/3 B/pixel")):
             kms = prof[key][0] / args.steps
             if kms > 0:
                 gbs = bpp * px_step / (kms * 1e-3) / 1e9

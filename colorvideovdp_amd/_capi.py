@@ -72,6 +72,7 @@ class YuvFormat(C.Structure):
 SYMBOLS = {
     "cvvdp_abi_version": (C.c_int, []),
     "cvvdp_build_flags": (C.c_int, []),
+    "cvvdp_fused_levels": (C.c_int, [C.c_void_p]),
     "cvvdp_struct_sizes": (None, [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "cvvdp_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_void_p)]),
     "cvvdp_destroy": (None, [C.c_void_p]),

@@ -513,6 +513,7 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
 }
 
 size_t cvvdp_workspace_bytes(const cvvdp_handle* h) { return (h && h->configured) ? h->ws_floats * sizeof(float) : 0; }
+int cvvdp_fused_levels(const cvvdp_handle* h) { return (h && h->configured) ? (h->pipeline ? 0 : h->fuse_levels) : -1; }
 
 int cvvdp_bind_workspace(cvvdp_handle* h, void* dev, size_t bytes) {
   if (!h || !h->configured) return fail(h, CVVDP_E_STATE, "configure first");

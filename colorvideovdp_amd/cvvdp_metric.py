@@ -798,6 +798,11 @@ class cvvdp(vq_metric):
         off = ptr.value - self._ws.data_ptr()
         return self._ws[off:off + n.value * 4].view(torch.float32)
 
+    @property
+    def fused_levels(self):
+        """Leading pyramid levels of the clip scored last whose band kernel computed the next level itself (band4f.hip)."""
+        return int(_capi.lib().cvvdp_fused_levels(self._handle))
+
     def profile(self, enable=True, per_call=False):
         """HIP-event timing of the kernel families ("hipEvent timings exposed in stats").  per_call=True: every
         predict() / predict_video_source() afterwards carries stats["kernel_ms"] = {family: milliseconds of that call}

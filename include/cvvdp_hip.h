@@ -140,6 +140,9 @@ const char* cvvdp_last_error(const cvvdp_handle* h);
 /* Start of predict_video_source for one clip or frame-range shard (cvvdp_metric.py:304-372). */
 int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip);
 size_t cvvdp_workspace_bytes(const cvvdp_handle* h);
+/* How many leading pyramid levels of the configured clip run the band kernel that computes the next level itself (no reduce pass
+ * for them; cvvdp_clip.fuse_mode).  For reporting (bench.py prices the path's algorithmic bytes with it); -1 if not configured. */
+int cvvdp_fused_levels(const cvvdp_handle* h);
 int cvvdp_bind_workspace(cvvdp_handle* h, void* dev_workspace, size_t bytes);
 
 /* Image frame supply + display model: video_source_array._get_frame (video_source.py:320-346),

@@ -14,10 +14,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PIX = 3840 * 2160 * 64
 KERNELS = {
-    # key: (substring of the kernel name, workgroups of the level-0 launch, algorithmic bytes per launch, what they are)
-    "temporal_fir": ("k_fir_rot<3, 17>", None, PIX * (24 + 32.0), "24 B/pixel in (fp32 RGB, test + reference) + 32 B/pixel out (8 level-0 planes)"),
-    "pyr_reduce_l0": ("k_reduce2", None, PIX * (32 + 8 + 2.0), "levels 0 -> 1 -> 2 in one pass: 32 B/pixel in, 8 + 2 B/pixel out"),
-    "band_level0": ("k_band4<4, false, false, false, false>", None, PIX * 40.0, "g0 (32 B/pixel) + g1 (8 B/pixel) in; partial sums out"),
+    # key: (substrings of the kernel names whose largest launches are ADDED, algorithmic bytes per step, what they are)
+    "temporal_fir": (["k_fir_rot<3, 17>"], PIX * (24 + 32.0), "24 B/pixel in (fp32 RGB, test + reference) + 32 B/pixel out (8 level-0 planes)"),
+    "band_level0": (["k_band4f<4, false>", "k_band4f<4, true>"], PIX * 40.0,
+                    "k_band4f: g0 (32 B/pixel) in, g1 (8 B/pixel) out; two launches (strips inside the image / strips at its left and right border)"),
+    "band_level1": (["k_band4f<4, false>#2", "k_band4f<4, true>#2"], PIX * 10.0, "k_band4f at level 1: g1 in, g2 out"),
 }
 
 
@@ -32,28 +33,36 @@ def rows(path, counter):
     return out
 
 
-def biggest(table, sub):
-    best = None
+def ranked(table, sub):
+    """launch sizes of the kernel whose name contains `sub`, largest (workgroups x bytes) first: [(workgroups, dispatches, per dispatch)]"""
+    out = []
     for name, lst in table.items():
         if sub in name:
-            for wg, disp, per in lst:
-                if best is None or wg * per > best[0] * best[2]:
-                    best = (wg, disp, per)
-    return best
+            out += lst
+    return sorted(out, key=lambda r: -r[0] * r[2])
+
+
+def pick(table, spec):
+    sub, _, nth = spec.partition("#")
+    r = ranked(table, sub)
+    n = int(nth) - 1 if nth else 0
+    return r[n] if len(r) > n else None
 
 
 def main(tag):
     fe = rows(os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch_size.txt"), "FETCH_SIZE")
     wr = rows(os.path.join(ROOT, "profiles", f"{tag}_pmc_write_size.txt"), "WRITE_SIZE")
     kernels = {}
-    for key, (sub, _, algo, what) in KERNELS.items():
-        f, w = biggest(fe, sub), biggest(wr, sub)
-        if f is None:
+    for key, (specs, algo, what) in KERNELS.items():
+        fs, ws = [pick(fe, sp) for sp in specs], [pick(wr, sp) for sp in specs]
+        if any(f is None for f in fs):
             continue
-        hbm = f[2] * 1024 * 2 + (w[2] * 1024 if w else 0.0)
-        kernels[key] = {"kernel": sub, "workgroups": f[0], "FETCH_SIZE_KB_per_launch": f[2], "WRITE_SIZE_KB_per_launch": w[2] if w else None,
-                        "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": algo, "measured_over_algorithmic": round(hbm / algo, 4),
-                        "algorithmic_bytes": what, "launches_sampled": f[1]}
+        fetch_kb = sum(f[2] for f in fs)
+        write_kb = sum(w[2] for w in ws if w)
+        hbm = fetch_kb * 1024 * 2 + write_kb * 1024
+        kernels[key] = {"kernel": " + ".join(sp.partition("#")[0] for sp in specs), "workgroups": [f[0] for f in fs], "FETCH_SIZE_KB_per_launch": fetch_kb,
+                        "WRITE_SIZE_KB_per_launch": write_kb, "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": algo,
+                        "measured_over_algorithmic": round(hbm / algo, 4), "algorithmic_bytes": what, "launches_sampled": fs[0][1]}
     # what the counters were measured on: written next to them ON THE GPU BOX by tools/refresh_profiles.sh (bench.code_stamp():
     # SHA-256 of the kernel sources + header, and of the library binary).  bench.py quotes the counters only for the same sources.
     stamp = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_stamp.json")))

@@ -23,7 +23,7 @@
 //     them -- the top segment starts at row 0 and writes rows 1..6 into their mirror slots too, the bottom segment copies the
 //     mirrored slot (reflect padding of the blurred map = the mirrored row of the horizontally blurred map).
 //
-// Used by launch_band (core.cpp) for W % 8 == 0, no heat map / dump / features; everything else keeps k_band4 + the reduce pass.
+// Used by launch_band (core.cpp) for even W, no heat map / dump / features; everything else keeps k_band4 + the reduce pass.
 // The streamed loads are hand-managed like k_band4's (six per row: four neighbour loads of row s+6, two row loads of row s+7;
 // one uniform `s_waitcnt vmcnt(2)` per step); tools/check_band4_isa.py checks this kernel's assembly too.
 #include <type_traits>
@@ -53,11 +53,16 @@ __device__ __forceinline__ void f_lds_write4(float* p, const float (&v)[4]) {
 
 }  // namespace
 
-// EDGE: the launch holds the strips that touch the left or right image border (strip 0 and the last one or two); the other strips run
-// the instantiation without any of the border code (zero masks, first / last column taps, replicas, blur mirrors), as a second
-// launch beside it.
-template <int NCH, bool EDGE>
+// EDGE != 0: the launch holds the strips that touch the left or right image border (strip 0 and the last one or two); the other strips
+// run the instantiation without any of the border code (zero masks, first / last column taps, replicas, blur mirrors), as a second
+// launch beside it.  EDGE == 1: W % 4 == 0 (every lane inside the image holds four columns).  EDGE == 2: W % 4 == 2 -- the lane of
+// columns W-2, W-1 is a PARTIAL lane: its 16-byte load is clamped to the row's last four columns and shifted into place (the two
+// columns right of the image become the reduce's zero padding), it owns ONE coarse column (the last one: the first / last column
+// rule moves from the lane's second coarse column to its first), stores one level-(l+1) sample instead of two, the blur's reflect
+// padding is written column by column, and its two columns outside the image are masked out of the pooling.
+template <int NCH, int EDGE>
 __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
+  constexpr bool RAG = EDGE == 2;
   constexpr int NP = 2 * NCH;
   __shared__ __attribute__((aligned(16))) float2 s_ve[2][NP][F_VE / 2];
   __shared__ __attribute__((aligned(16))) float s_lum[2][256];            // 1/L_T, 1/L_R
@@ -81,7 +86,8 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   const int fc0 = x0 - F_HALO + 4 * j;
   const bool in_img = fc0 >= 0 && fc0 < W;
   const bool edge_r = x0 + F_SW + F_HALO > W;
-  constexpr bool edge_lr = EDGE;                    // (launch_band4f deals the strips accordingly)
+  constexpr bool edge_lr = EDGE != 0;               // (launch_band4f deals the strips accordingly)
+  const bool part = RAG && in_img && fc0 + 4 > W;   // the partial lane (fc0 == W - 2)
   const bool interior = j >= 2 && j < 62 && fc0 < W;
   const int cb = (x0 - F_HALO) / 2;
   const int ys = seg * a.seg_h, ye = min(H, ys + a.seg_h);
@@ -110,9 +116,11 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   float xw0 = a.xw[0 * 4 + c], xw1 = a.xw[1 * 4 + c], xw2 = a.xw[2 * 4 + c], xw3 = a.xw[3 * 4 + c];
   float m1c = a.m1[c];
   float inv_dmax = a.inv_dmax;
-  F_IN_VGPR(ind_k0); F_IN_VGPR(xw1); F_IN_VGPR(xw2); F_IN_VGPR(xw3); F_IN_VGPR(m1c); F_IN_VGPR(inv_dmax);
-  F_IN_VGPR(e0); F_IN_VGPR(e1); F_IN_VGPR(eo); F_IN_VGPR(mask_p); F_IN_VGPR(eps_p);
-  F_IN_VGPR(qc); F_IN_VGPR(ind_k1); F_IN_VGPR(xw0);
+  if constexpr (!RAG) {   // (the EDGE == 2 instantiation is short of VGPRs instead: its constants stay scalar, spilled or not)
+    F_IN_VGPR(ind_k0); F_IN_VGPR(xw1); F_IN_VGPR(xw2); F_IN_VGPR(xw3); F_IN_VGPR(m1c); F_IN_VGPR(inv_dmax);
+    F_IN_VGPR(e0); F_IN_VGPR(e1); F_IN_VGPR(eo); F_IN_VGPR(mask_p); F_IN_VGPR(eps_p);
+    F_IN_VGPR(qc); F_IN_VGPR(ind_k1); F_IN_VGPR(xw0);
+  }
 #undef F_IN_VGPR
 
   // ---- the reduce's lane constants.  Samples outside the image are the reference's zero padding: addresses are clamped, the
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   // (the zero masks and the first / last column's extra taps are made from fc0 inside the edge_lr branches: nothing of them is live in
   // the strips away from the image border)
   const int lane_first = 2;                                       // strip 0: the lane of fine column 0
-  const int lane_last = (W - 4 - (x0 - F_HALO)) >> 2;             // the lane of fine columns W-4 .. W-1 (edge_r strips: 0 .. 63)
+  const int lane_last = (W - (RAG ? 2 : 4) - (x0 - F_HALO)) >> 2;  // the lane of the last fine columns (edge_r strips: 0 .. 63)
 
   float4 cA = make_float4(0, 0, 0, 0), cB = cA, cC = cA;          // coarse rows my-1, my, my+1 of this lane's two coarse columns: (T0, T1, R0, R1)
   float4 rP = cA, rQ = cA;                                        // partial sums of the two coarse rows under construction (older, younger)
@@ -148,10 +156,12 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   // One level-l row (four own samples + three neighbours per plane) through the horizontal pass, then into the running sums.
   // a_row: its index (scalar).  Returns true and the completed coarse row (a_row/2 - 1) on even rows.
   auto consume = [&](int a_row, auto odd_a, v4f vT, v4f vR, v2f lT, float rT, v2f lR, float rR, float4& emitted) {
+    int fcx = fc0;
+    if constexpr (RAG) asm volatile("" : "+v"(fcx));   // EDGE == 2 is out of VGPRs: its lane masks and edge weights are re-made from fc0 row by row
     if constexpr (edge_lr) {
-      const float mV = in_img ? 1.0f : 0.0f;
-      const float mL = (fc0 - 2 >= 0 && fc0 - 2 < W) ? 1.0f : 0.0f;
-      const float mR = (fc0 + 4 >= 0 && fc0 + 4 < W) ? 1.0f : 0.0f;
+      const float mV = (RAG ? (fcx >= 0 && fcx < W) : in_img) ? 1.0f : 0.0f;
+      const float mL = (fcx - 2 >= 0 && fcx - 2 < W) ? 1.0f : 0.0f;
+      const float mR = (fcx + 4 >= 0 && fcx + 4 < W) ? 1.0f : 0.0f;
       vT *= mV; vR *= mV; lT *= mL; lR *= mL; rT *= mR; rR *= mR;
     }
     float4 hr;
@@ -161,12 +171,18 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
     hr.w = __builtin_fmaf(rR, rk4, __builtin_fmaf(vR.w, rk3, __builtin_fmaf(vR.z, rk2, __builtin_fmaf(vR.y, rk1, vR.x * rk0))));
     if constexpr (edge_lr) {
       // first / last output column (lpyr_dec.py:205-209; the last column's extra taps depend on the ROW parity, sic)
-      const float wl1 = fc0 == 0 ? rk1 : 0.0f, wl0 = fc0 == 0 ? rk0 : 0.0f;
-      const float wr3 = fc0 == W - 4 ? ((H & 1) ? rk3 : rk4) : 0.0f, wr2 = (fc0 == W - 4 && (H & 1)) ? rk4 : 0.0f;
+      const float wl1 = fcx == 0 ? rk1 : 0.0f, wl0 = fcx == 0 ? rk0 : 0.0f;
+      const bool last_lane = fcx == W - (RAG ? 2 : 4);              // the lane of columns W-2, W-1
+      const float wr3 = last_lane ? ((H & 1) ? rk3 : rk4) : 0.0f, wr2 = (last_lane && (H & 1)) ? rk4 : 0.0f;
       hr.x = __builtin_fmaf(vT.y, wl0, __builtin_fmaf(vT.x, wl1, hr.x));
       hr.z = __builtin_fmaf(vR.y, wl0, __builtin_fmaf(vR.x, wl1, hr.z));
-      hr.y = __builtin_fmaf(vT.z, wr2, __builtin_fmaf(vT.w, wr3, hr.y));
-      hr.w = __builtin_fmaf(vR.z, wr2, __builtin_fmaf(vR.w, wr3, hr.w));
+      if constexpr (RAG) {                                          // columns W-2, W-1 are the partial lane's first two: its coarse column X0
+        hr.x = __builtin_fmaf(vT.x, wr2, __builtin_fmaf(vT.y, wr3, hr.x));
+        hr.z = __builtin_fmaf(vR.x, wr2, __builtin_fmaf(vR.y, wr3, hr.z));
+      } else {
+        hr.y = __builtin_fmaf(vT.z, wr2, __builtin_fmaf(vT.w, wr3, hr.y));
+        hr.w = __builtin_fmaf(vR.z, wr2, __builtin_fmaf(vR.w, wr3, hr.w));
+      }
     }
     // Vertical pass.  Rows outside the image are the zero padding (nothing to add); the first / last coarse row's extra taps
     // (lpyr_dec.py:195-199) are added in uniform branches that only the image's first and last two rows take.
@@ -207,17 +223,25 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
           if (rep_left) emitted = make_float4(t0, t0, r0_, r0_);
         }
         if (edge_r) {
-          const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, emitted.y), lane_last));
-          const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, emitted.w), lane_last));
+          const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, RAG ? emitted.x : emitted.y), lane_last));
+          const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, RAG ? emitted.z : emitted.w), lane_last));
           if (rep_right) emitted = make_float4(t1, t1, r1, r1);
+          if constexpr (RAG) {
+            if (part) { emitted.y = t1; emitted.w = r1; }            // the partial lane's second coarse column is column Wc already
+          }
         }
       }
       // level l+1 belongs to the lanes that own its columns (interior of the strip) in the segment that owns its rows
       const int own_end = seg == a.n_seg - 1 ? Hc : (ye >> 1);
       if (interior && m1 >= (ys >> 1) && m1 < own_end) {
         const int64_t o = (int64_t)m1 * Wc + (cb + 2 * j);
-        __builtin_nontemporal_store(v2f{emitted.x, emitted.y}, reinterpret_cast<v2f*>(g1T + o));
-        __builtin_nontemporal_store(v2f{emitted.z, emitted.w}, reinterpret_cast<v2f*>(g1R + o));
+        if (RAG && part) {
+          __builtin_nontemporal_store(emitted.x, g1T + o);
+          __builtin_nontemporal_store(emitted.z, g1R + o);
+        } else {
+          __builtin_nontemporal_store(v2f{emitted.x, emitted.y}, reinterpret_cast<v2f*>(g1T + o));
+          __builtin_nontemporal_store(v2f{emitted.z, emitted.w}, reinterpret_cast<v2f*>(g1R + o));
+        }
       }
     }
   };
@@ -294,6 +318,9 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
       const float r0 = fast_rcp(T.x), r1 = fast_rcp(T.y);
       De[2 * h] = __builtin_fmaf(X.x, r0, kEps); De[2 * h + 1] = __builtin_fmaf(X.y, r1, kEps);
     }
+    if constexpr (RAG) {
+      if (part) { De[2] = 0.0f; De[3] = 0.0f; }                        // columns right of the image do not exist: no term
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc = __builtin_fmaf(De[i], De[i], acc);   // sum of (D + eps)^2; k_finalize takes the eps^2 off
   };
@@ -316,10 +343,10 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   auto rowc = [&](int r) { return min(max(r, 0), H - 1); };       // rows outside the image: any valid row (their weight is 0)
 
   // image-edge mirror roles of the contrast stage (band4.hip): reflect padding of the blur at the left / right image border
-  const bool mir_block = EDGE && (strip == 0 || edge_r);
+  const bool mir_block = EDGE != 0 && (strip == 0 || edge_r);
   int mir_kind = 0, mir_base = 0;
   if (strip == 0 && (fc0 == 0 || fc0 == 4)) { mir_kind = fc0 == 0 ? 1 : 2; mir_base = F_HALO - (fc0 == 0 ? 1 : 4); }
-  if (fc0 == W - 8 || fc0 == W - 4) {
+  if (!RAG && (fc0 == W - 8 || fc0 == W - 4)) {
     const int base = 2 * (W - 1) - (fc0 + (fc0 == W - 8 ? 1 : 0)) - (x0 - F_HALO);
     if (base < 256) { mir_kind = fc0 == W - 8 ? 1 : 2; mir_base = base; }
   }
@@ -327,7 +354,10 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   // ---- prologue: rows r_start-4 .. r_start+4 prime the reduce (three complete coarse rows in the window, two partial ones),
   // rows r_start .. r_start+4 stay in ring slots 0 .. 4, the rows after them are requested
   {
-    auto ld4 = [&](const float* plane, int r) -> v4f { return *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(plane + (int64_t)rowc(r) * W) + goff); };
+    auto ld4 = [&](const float* plane, int r) -> v4f {
+      return *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(plane + (int64_t)rowc(r) * W) + goff);
+    };
+    auto placed = [&](v4f q) -> v4f { return part ? v4f{q.z, q.w, 0.0f, 0.0f} : q; };   // (part is false at compile time unless EDGE == 2)
     auto ld2 = [&](const float* plane, int r) -> v2f { return *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(plane + (int64_t)rowc(r) * W) + loff); };
     auto ld1 = [&](const float* plane, int r) -> float { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane + (int64_t)rowc(r) * W) + roff); };
     float4 em = cC;
@@ -337,11 +367,11 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
       const v4f vT = ld4(gT, ar), vR = ld4(gR, ar);
       const v2f lT = ld2(gT, ar), lR = ld2(gR, ar);
       const float rT = ld1(gT, ar), rR = ld1(gR, ar);
-      if (i >= 4) { ringT[i - 4] = vT; ringR[i - 4] = vR; }
+      if (i >= 4) { ringT[i - 4] = vT; ringR[i - 4] = vR; }          // (the ring holds the rows as loaded)
       if (i & 1) {
-        consume(ar, std::true_type{}, vT, vR, lT, rT, lR, rR, em);
+        consume(ar, std::true_type{}, placed(vT), placed(vR), lT, rT, lR, rR, em);
       } else {
-        consume(ar, std::false_type{}, vT, vR, lT, rT, lR, rR, em);
+        consume(ar, std::false_type{}, placed(vT), placed(vR), lT, rT, lR, rR, em);
         cA = cB; cB = cC; cC = em;
       }
     }
@@ -368,7 +398,10 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
     (void)&ringT; (void)&ringR; (void)&nbLT; (void)&nbLR; (void)&nbRT; (void)&nbRR; (void)&goff; (void)&loff; (void)&roff; (void)&gT; (void)&gR; (void)&W;
     asm volatile("s_waitcnt vmcnt(2)" : "+v"(ringT[(U + 5) & 7]), "+v"(ringR[(U + 5) & 7]), "+v"(nbLT[(U + 5) & 1]), "+v"(nbLR[(U + 5) & 1]),
                  "+v"(nbRT[(U + 5) & 1]), "+v"(nbRR[(U + 5) & 1]));
-    const v4f pT = ringT[U], pR = ringR[U];
+    // (EDGE == 2: the partial lane's rows are shifted into place where they are USED, twice per row -- a ring register that is
+    // rewritten stops being pinned, and the compiler then copies ring registers around while their loads are in flight)
+    auto placed = [&](v4f q) -> v4f { return part ? v4f{q.z, q.w, 0.0f, 0.0f} : q; };
+    const v4f pT = placed(ringT[U]), pR = placed(ringR[U]);
     // ================= phase 1
     const int yprev = r - 1 - F_R;
     if (interior && yprev >= ys) stage3c(k7);
@@ -396,11 +429,23 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
           float* dst = &s_m[c][mir_base];
           dst[0] = v0; dst[-1] = v1; dst[-2] = v2;
         }
+        if constexpr (RAG) {                              // columns W-7 .. W-2, wherever they fall in the lanes, to 2(W-1)-x (band4.hip, mir_any)
+          if (edge_r) {
+            // (one address register and four immediate offsets: element idx - i of column fc0 + i is p3[3 - i])
+            const int idx0 = 2 * (W - 1) - fc0 - (x0 - F_HALO);
+            float* p3 = &s_m[c][0] + (idx0 - 3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int x = fc0 + i;
+              if (x >= W - 1 - F_R && x <= W - 2 && idx0 - i < 256) p3[3 - i] = m[i];
+            }
+          }
+        }
       }
     }
     // level-l row r+5 into the reduce; an even row completes a coarse row, which rolls the window for row r+1 (even) below
     float4 emitted = cC;
-    consume(r + 5, std::integral_constant<bool, !ODD>{}, ringT[(U + 5) & 7], ringR[(U + 5) & 7], nbLT[(U + 5) & 1], nbRT[(U + 5) & 1],
+    consume(r + 5, std::integral_constant<bool, !ODD>{}, placed(ringT[(U + 5) & 7]), placed(ringR[(U + 5) & 7]), nbLT[(U + 5) & 1], nbRT[(U + 5) & 1],
             nbLR[(U + 5) & 1], nbRR[(U + 5) & 1], emitted);
     coarse_finish(ODD ? 0 : 1, std::integral_constant<bool, !ODD>{}, ODD, emitted);   // vertical expand of row r+1
     __syncthreads();
@@ -536,7 +581,7 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
 #undef F_LOAD1
 #undef F_DRAIN
 
-bool band4f_supported(int H, int W) { return (W & 7) == 0 && W >= 32 && H >= 32; }
+bool band4f_supported(int H, int W) { return (W & 1) == 0 && W >= 32 && H >= 32; }
 
 // strips whose 256 columns x0-8 .. x0+247 reach past the right image border (trailing; at least the last one)
 static int band4f_right_edge_strips(int W, int n_strip) {
@@ -550,11 +595,12 @@ void launch_band4f(const BandArgs& a0, hipStream_t s, hipStream_t s_edge) {
   const int n_edge = std::min(a.n_strip, 1 + band4f_right_edge_strips(a.W, a.n_strip));   // strip 0 + the right-edge strips
   a.strip0 = 0; a.n_strip_l = n_edge;
   a.per_xcd = (a.n_strip_l * a.n_seg * a.items + 7) / 8;
-  hipLaunchKernelGGL((k_band4f<4, true>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);     // video only (core.cpp)
+  if ((a.W & 3) == 0) hipLaunchKernelGGL((k_band4f<4, 1>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);     // video only (core.cpp)
+  else hipLaunchKernelGGL((k_band4f<4, 2>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);
   if (n_edge < a.n_strip) {
     a.strip0 = 1; a.n_strip_l = a.n_strip - n_edge;
     a.per_xcd = (a.n_strip_l * a.n_seg * a.items + 7) / 8;
-    hipLaunchKernelGGL((k_band4f<4, false>), dim3(8 * a.per_xcd), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_band4f<4, 0>), dim3(8 * a.per_xcd), dim3(256), 0, s, a);
   }
 }
 

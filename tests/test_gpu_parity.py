@@ -811,6 +811,15 @@ def _fuse_clip(W, H, F, seed):
     (1200, 90, 3, 50, "standard_4k"),         # W a multiple of the strip width, few rows: top and bottom mirrors in one segment
     (248, 600, 3, 60, "standard_hdr_pq"),     # a strip whose 256 columns end exactly at the image; tall
     (152, 69, 12, 30, "standard_fhd"),        # segments of 14 rows: shorter than two blur radii, the last one 13 rows
+    # W % 8 != 0 (even widths): the border strips' instantiation with a partial lane (W % 4 == 2) / the aligned one at W % 8 == 4
+    (1366, 200, 3, 60, "standard_4k"),        # the laptop width: six strips, level 0 fused (683 columns at level 1: odd, reduce pass)
+    (854, 97, 2, 30, "standard_fhd"),         # 480p width, odd height
+    (254, 144, 4, 30, "standard_fhd"),        # two strips, the second 14 columns wide
+    (486, 130, 3, 60, "standard_4k"),         # TWO strips reach the right border (x0 = 240: 488 > 486, x0 = 480: six columns)
+    (38, 50, 3, 24, "standard_fhd"),          # one strip that is left and right border at once
+    (250, 301, 2, 60, "standard_hdr_pq"),     # the first strip ends two columns short of the image; odd height
+    (492, 100, 3, 30, "standard_fhd"),        # W % 8 == 4: level 0 on the aligned border kernel, level 1 (246) on the partial-lane one
+    (36, 33, 2, 30, "standard_fhd"),          # W % 8 == 4, the smallest fusable frame there is
 ])
 def test_fused_reduce_band_kernels(W, H, F, fps, disp):
     import colorvideovdp_amd as cv

@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
-"""Safety check of the hand-managed stream loads in csrc/band4.hip (see STREAM LOADS there).
+"""Safety check of the hand-managed stream loads in csrc/band4.hip and csrc/band4f.hip (see STREAM LOADS there).
 
-The g-row / coarse-row loads of k_band4 are issued from inline assembly and waited for with explicit
+The g-row / coarse-row loads of k_band4 and the ring / neighbour loads of k_band4f are issued from inline assembly and waited for with explicit
 `s_waitcnt vmcnt(N)`; the compiler does not know that their destination registers are "in flight" in between.
 This script reads the generated assembly and checks, for every loop of every k_band4 instantiation, that no
 instruction reads or writes a destination register of a stream load between the load and the wait that covers
 it (walking each loop body twice in layout order, so that the back edge is covered, and then the whole kernel once in
 layout order for the straight-line code between the loops; loads return in order, so `vmcnt(N)` retires all but the N
-youngest).  `make` runs it on the assembly of the very build it links (csrc/Makefile: band4.isa.ok).
+youngest; spill reloads and stores are vector-memory operations too and sit in the same queue).  `make` runs it on the assembly
+of the very build it links (csrc/Makefile: band4.isa.ok).  The walk is in LAYOUT order: it relies on the compiler keeping a loop's
+blocks together, which it does for these kernels as written; a control-flow-graph version (tools/experimental/) was tried and
+drowns in paths the structuriser creates but no execution takes (profiles/r03_dev_notes.txt 12).
 
     tools/isa_band4.sh && python tools/check_band4_isa.py [/tmp/isa/band4_new.s]
 """
@@ -51,7 +54,11 @@ def _walk(name, body, passes, what):
                 dst = set(regs(code.split(None, 1)[1].split(",")[0]))
                 queue.append((dst, code))
                 n_loads += it == 0
-            elif op.startswith(("global_store", "buffer_store")):
+            elif op.startswith(("scratch_load", "buffer_load", "flat_load")):
+                # a spill reload (or any other vector-memory load) is one more operation in the vmcnt queue: younger than the
+                # hand-issued loads before it, so the exact counts of the hand-written waits no longer cover those
+                queue.append((set(regs(code.split(None, 1)[1].split(",")[0])), code))
+            elif op.startswith(("global_store", "buffer_store", "scratch_store", "flat_store")):
                 queue.append((set(), code))      # stores count in vmcnt on gfx9
     return bad, n_loads
 

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """ISA-derived VALU budget of k_band4<4> (the level-0 band kernel): instruction counts per stage of the steady-state row loop, read
 from the assembly of the build (colorvideovdp_amd/csrc/build/band4.s, written by `make`), priced with the per-instruction costs
-measured on MI355X (profiles/r01_ubench_valu_rates.txt: ns per wave64 instruction per SIMD).
+measured on MI355X (profiles/r01_ubench_valu_rates.txt: ns per wave64 instruction per SIMD; except v_cndmask: that file's 9.9 ns was
+the micro-benchmark's own serial VCC dependence -- taking four v_cndmask per row out of k_band4f changed its time by nothing
+(profiles/r03_dev_notes.txt 12), so a select is priced like the other one-pass integer / compare operations).
 
     python tools/isa_budget_band4.py [band4.s] > profiles/r03_band4_isa_budget.txt
+    python tools/isa_budget_band4.py --fused [band4f.s] > profiles/r03_band4f_isa_budget.txt     (k_band4f<4, 0>: eight rows per loop trip)
 """
 import collections
 import os
@@ -13,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = "_ZN5cvvdp7k_band4ILi4ELb0ELb0ELb0ELb0EEEvNS_8BandArgsE"
 COST = {"packed fp32 (v_pk_*)": 2.17, "transcendental (exp/log/rcp)": 3.47, "v_fma / v_fmaak": 1.75, "v_fmac": 1.59,
-        "add/sub/mul/mov": 1.2, "min/max/med3/cvt/other": 1.8, "v_cndmask": 9.9}
+        "add/sub/mul/mov": 1.2, "min/max/med3/cvt/other": 1.8, "v_cndmask": 1.8}
 
 
 def cls(op):
@@ -32,7 +35,11 @@ def cls(op):
     return "min/max/med3/cvt/other"
 
 
-def main(path):
+def main(path, fused=False):
+    global KERNEL
+    rows_per_trip, n_bar = 2, 4
+    if fused:
+        KERNEL, rows_per_trip, n_bar = "_ZN5cvvdp8k_band4fILi4ELi0EEEvNS_8BandArgsE", 8, 16
     L = open(path).read().split("\n")
     s = next(i for i, l in enumerate(L) if l.startswith(KERNEL + ":"))
     e = next(i for i in range(s, len(L)) if ".end_amdhsa_kernel" in L[i])
@@ -45,7 +52,7 @@ def main(path):
             loops.append((labels[m.group(1)], i))
     # the steady-state loop (rows inside the image, rolling coarse window): the inner loop with the fewest instructions among the
     # row-pair loops (the reflected-row copy reloads the coarse window: three more loads per row)
-    big = [(hi - lo, lo, hi) for lo, hi in loops if sum(1 for x in K[lo:hi] if "s_barrier" in x) == 4]
+    big = [(hi - lo, lo, hi) for lo, hi in loops if sum(1 for x in K[lo:hi] if "s_barrier" in x) == n_bar]
     _, lo, hi = min(big)
     segs, cur = [], []
     for l in K[lo:hi + 1]:
@@ -68,6 +75,8 @@ def main(path):
         nv = sum(v for k, v in ops.items() if k.startswith("v_"))
         if nv == 0:
             return None
+        if fused and ops["v_fmac_f32_e32"] + ops["v_fma_f32"] >= 24 and ops["v_min_f32_e32"] + ops["v_min_f32_e64"] < 8 and ops["v_rcp_f32_e32"] < 4 and ops["v_pk_fma_f32"] < 20:
+            return "reduce of row r+5: horizontal 5-tap of 2 coarse columns x 2 planes, running vertical sums (+ window roll / level l+1 store on even rows)"
         if ops["v_rcp_f32_e32"] >= 4:
             return "pooling stage of row r-7: 1+M (packed), X = d^p - eps^p, D = X/((1+M) + X/dmax), sum D(D+2eps)"
         if ops["v_log_f32_e32"] == 1 and ops["v_exp_f32_e32"] == 4:
@@ -89,7 +98,7 @@ def main(path):
         return "other"
 
     print(f"# ISA-derived VALU budget of {KERNEL}")
-    print(f"# steady-state row-PAIR loop (even row, odd row), lines {lo}..{hi} of the kernel in {os.path.relpath(path, ROOT)}")
+    print(f"# steady-state loop of {rows_per_trip} rows per trip, lines {lo}..{hi} of the kernel in {os.path.relpath(path, ROOT)}")
     print("# cost model: ns per wave64 instruction per SIMD, profiles/r01_ubench_valu_rates.txt  " + ", ".join(f"{k} {v}" for k, v in COST.items()))
     print("#")
     print(f"# {'stage':100s} VALU   ns(model)  LDS  SALU  VMEM   classes")
@@ -127,12 +136,16 @@ def main(path):
             interior_ns += t
             interior_v += nv
     print("#")
-    print(f"# per row pair: {tot_v} VALU instructions in the loop body, {interior_v} on the path of a strip that touches no image edge "
-          f"({interior_v / 2:.1f} per wave-row), {interior_ns / 2:.0f} ns per wave-row by the cost model")
-    print("# classes per row pair: " + ", ".join(f"{k} {v}" for k, v in sorted(tot.items())))
+    print(f"# per loop trip ({rows_per_trip} rows): {tot_v} VALU instructions in the loop body, {interior_v} on the path of a strip that touches no image edge "
+          f"({interior_v / rows_per_trip:.1f} per wave-row), {interior_ns / rows_per_trip:.0f} ns per wave-row by the cost model")
+    print("# classes per loop trip: " + ", ".join(f"{k} {v}" for k, v in sorted(tot.items())))
+    if fused:
+        return
     print("# measured (profiles/r02_pmc_sq_counters.txt): 10.38 M clocks per launch = 1092 clocks = ~590 ns per wave-row and SIMD at 3 waves / SIMD;")
     print("# the model's VALU time is ~72 % of that: the rest is LDS / barrier latency that three waves do not cover, strip and segment halos (10 %).")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "colorvideovdp_amd", "csrc", "build", "band4.s"))
+    args = [x for x in sys.argv[1:] if x != "--fused"]
+    fused = "--fused" in sys.argv[1:]
+    main(args[0] if args else os.path.join(ROOT, "colorvideovdp_amd", "csrc", "build", "band4f.s" if fused else "band4.s"), fused)

@@ -16,9 +16,9 @@ PIX = 3840 * 2160 * 64
 KERNELS = {
     # key: (substrings of the kernel names whose largest launches are ADDED, algorithmic bytes per step, what they are)
     "temporal_fir": (["k_fir_rot<3, 17>"], PIX * (24 + 32.0), "24 B/pixel in (fp32 RGB, test + reference) + 32 B/pixel out (8 level-0 planes)"),
-    "band_level0": (["k_band4f<4, false>", "k_band4f<4, true>"], PIX * 40.0,
+    "band_level0": (["k_band4f<4, 0>", "k_band4f<4, 1>"], PIX * 40.0,
                     "k_band4f: g0 (32 B/pixel) in, g1 (8 B/pixel) out; two launches (strips inside the image / strips at its left and right border)"),
-    "band_level1": (["k_band4f<4, false>#2", "k_band4f<4, true>#2"], PIX * 10.0, "k_band4f at level 1: g1 in, g2 out"),
+    "band_level1": (["k_band4f<4, 0>#2", "k_band4f<4, 1>#2"], PIX * 10.0, "k_band4f at level 1: g1 in, g2 out"),
 }
 
 

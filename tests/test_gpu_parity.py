@@ -706,11 +706,20 @@ def test_large_ragged_frames_split_off_their_edge_strips():
     assert torch.equal(long.test[:, :, :8], short.test)
     m = cv.cvvdp(display_name="standard_4k")
     _, s_long = m.predict_video_source(long)
+    fused_long = m.fused_levels
     _, s_short = m.predict_video_source(short)
     np.testing.assert_allclose(s_long["Q_per_ch"][:, :, :8], s_short["Q_per_ch"], rtol=2e-5, atol=1e-7)
     # and blocks of the long clip do not change a bit (the split is a property of the clip, not of the block)
     _, s_blk = cv.cvvdp(display_name="standard_4k", block_frames=9).predict_video_source(long)
     np.testing.assert_array_equal(s_blk["Q_per_ch"], s_long["Q_per_ch"])
+    # Since the fused band kernels take even widths (W % 4 == 2 here: k_band4f<4, 2> on the border strips), level 0 of this clip
+    # is fused by the product's own choice; the unfused route (reduce pass + k_band4 with its edge strips split off) must agree.
+    assert fused_long == 1                           # level 1 is 1283 columns wide: odd, reduce pass
+    m2 = cv.cvvdp(display_name="standard_4k")
+    m2.fuse_mode = 2
+    _, s_unfused = m2.predict_video_source(long)
+    assert m2.fused_levels == 0
+    np.testing.assert_allclose(s_long["Q_per_ch"], s_unfused["Q_per_ch"], rtol=5e-5, atol=5e-7)
 
 
 def test_8k_pq_full_temporal_window_heatmap_and_distogram_against_reference():

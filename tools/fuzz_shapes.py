@@ -1,6 +1,7 @@
 """Randomised shape sweep of the HIP path against the CPU oracle (development aid, run on the GPU box):
     python tools/fuzz_shapes.py [n_cases] [seed]
-Random widths / heights (16..700 x 16..400, all residues mod 16), frame counts, frame rates, displays, padding and heat-map modes."""
+Random widths / heights (16..700 x 16..400, all residues mod 16), frame counts, frame rates, displays, padding and heat-map modes;
+every third video case without a heat map forces the fused band kernels (test hook fuse_mode = 1) wherever a level supports them."""
 import sys
 import numpy as np
 import torch
@@ -40,10 +41,12 @@ for k in range(n):
     o = orc.Oracle(display_name=disp, temp_padding=pad, heatmap=heat)
     oj, os_ = o.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
     m = cv.cvvdp(display_name=disp, temp_padding=pad, heatmap=heat, block_frames=int(rng.choice([1, 2, 64])))
+    fm = 1 if (F > 1 and not heat and rng.random() < 0.34) else 0
+    m.fuse_mode = fm
     j, s = m.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
     dq = np.abs(s["Q_per_ch"] - os_["Q_per_ch"]) / (np.abs(os_["Q_per_ch"]) * 2e-4 + 2e-6)
     dj = float(np.max(np.abs(np.atleast_1d(j.cpu().numpy()) - np.atleast_1d(np.asarray(oj)))))
-    msg = f"{k:3d} {W}x{H}x{F} B{B} {dt} C{test.shape[1]} fps {fps} {disp} {pad} heat {heat}: dJOD {dj:.2e}  Q err/tol {dq.max():.2f}"
+    msg = f"{k:3d} {W}x{H}x{F} B{B} {dt} C{test.shape[1]} fps {fps} {disp} {pad} heat {heat} fused {m.fused_levels if F > 1 else 0}: dJOD {dj:.2e}  Q err/tol {dq.max():.2f}"
     ok = dj <= 1e-3 and dq.max() <= 1.0
     if heat:
         a = s["heatmap"].numpy().astype(np.float32)

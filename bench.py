@@ -467,6 +467,13 @@ def main():
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "traffic_note": traffic_note, "avg_launch_ms": round(avg_ms, 4), "launches": n,
                            "algorithmic_bytes_per_launch": BAND0_BYTES_PER_PIXEL * W * H * frames_per_launch}
+        sq = ((ktraffic or {}).get("band_level0") or {}).get("sq")
+        if sq:
+            # what holds this kernel back when it is not the memory system (same stamped counter passes): it is a VALU / latency kernel --
+            # "bound": "hbm" above is the accounting the bench contract asks for, not a claim that HBM limits it
+            out["roofline"]["valu"] = {"busy": sq.get("valu_busy"), "instructions_per_launch": sq.get("valu_instructions_per_launch"),
+                                       "waves_waiting_frac": sq.get("waves_waiting_frac"), "workgroups": sq.get("workgroups"),
+                                       "source": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32), profiles/r03_pmc_sq_counters.txt"}
         # the other two dominant kernels on the same footing (algorithmic bytes per step / HIP-event time per step / 8 TB/s)
         px_step = W * H * count
         in_b = INPUT_BYTES_PER_PIXEL[dtype]

@@ -49,6 +49,37 @@ def pick(table, spec):
     return r[n] if len(r) > n else None
 
 
+def sq_of(tag, spec):
+    """SQ counters of one launch size of one kernel (profiles/<tag>_pmc_sq_counters.txt, tools/sq_counters.sh): shader clocks, VALU pipe
+    utilisation, VALU instructions -- what bounds a kernel that is not HBM-bound."""
+    path = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq_counters.txt")
+    if not os.path.isfile(path):
+        return None
+    sub, _, nth = spec.partition("#")
+    per = {}
+    for line in open(path):
+        f = line.split()
+        if line.startswith("#") or sub not in line:
+            continue
+        idx = [i for i, x in enumerate(f) if x.startswith("SQ_")]
+        if idx:
+            per.setdefault(int(f[idx[0] - 1]), {})[f[idx[0]]] = float(f[idx[0] + 3])
+    sizes = sorted(per, reverse=True)
+    n = int(nth) - 1 if nth else 0
+    if len(sizes) <= n or "SQ_BUSY_CYCLES" not in per[sizes[n]]:
+        return None
+    c = per[sizes[n]]
+    clocks = c["SQ_BUSY_CYCLES"] / 32
+    out = {"workgroups": sizes[n], "shader_clocks_per_launch": round(clocks), "note": "counter passes run the kernels one at a time"}
+    if "SQ_ACTIVE_INST_VALU" in c:
+        out["valu_busy"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * clocks), 3)      # 1024 SIMDs; the counter is in quad-cycles
+    if "SQ_INSTS_VALU" in c:
+        out["valu_instructions_per_launch"] = round(c["SQ_INSTS_VALU"])
+    if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
+        out["waves_waiting_frac"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3)
+    return out
+
+
 def main(tag):
     fe = rows(os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch_size.txt"), "FETCH_SIZE")
     wr = rows(os.path.join(ROOT, "profiles", f"{tag}_pmc_write_size.txt"), "WRITE_SIZE")
@@ -63,6 +94,9 @@ def main(tag):
         kernels[key] = {"kernel": " + ".join(sp.partition("#")[0] for sp in specs), "workgroups": [f[0] for f in fs], "FETCH_SIZE_KB_per_launch": fetch_kb,
                         "WRITE_SIZE_KB_per_launch": write_kb, "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": algo,
                         "measured_over_algorithmic": round(hbm / algo, 4), "algorithmic_bytes": what, "launches_sampled": fs[0][1]}
+        sq = sq_of(tag, specs[0])
+        if sq:
+            kernels[key]["sq"] = sq
     # what the counters were measured on: written next to them ON THE GPU BOX by tools/refresh_profiles.sh (bench.code_stamp():
     # SHA-256 of the kernel sources + header, and of the library binary).  bench.py quotes the counters only for the same sources.
     stamp = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_stamp.json")))

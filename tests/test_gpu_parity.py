@@ -858,6 +858,38 @@ def test_fused_reduce_band_kernels(W, H, F, fps, disp):
     np.testing.assert_allclose(q1, ostats["Q_per_ch"], rtol=2e-4, atol=2e-6)
 
 
+@pytest.mark.parametrize("dt", ["u16", "f16", "f32"])
+def test_fused_kernels_with_a_batch_and_other_sample_formats(dt):
+    """The work items of the fused band kernels are (frame, batch entry) pairs; the sample format only concerns the temporal kernel in
+    front of them.  A batch of two test clips against one broadcast reference (video_source.py:247-252), forced onto the fused kernels,
+    against the oracle and against the unfused route."""
+    import colorvideovdp_amd as cv
+    from oracle import cvvdp_oracle as orc
+    W, H, F = 502, 130, 4                                           # W % 4 == 2: three strips, the partial-lane border kernel
+    t8, r8 = _fuse_clip(W, H, F, 77)
+    rng = np.random.default_rng(78)
+    t = np.concatenate([t8, np.clip(t8.astype(np.int32) + rng.integers(-6, 7, t8.shape), 0, 255).astype(np.uint8)], axis=0).astype(np.float64) / 255.0
+    r = r8.astype(np.float64) / 255.0
+    if dt == "u16":
+        t, r = np.round(t * 65535).astype(np.uint16), np.round(r * 65535).astype(np.uint16)
+    elif dt == "f16":
+        t, r = torch.tensor(t.astype(np.float16)), torch.tensor(r.astype(np.float16))
+    else:
+        t, r = t.astype(np.float32), r.astype(np.float32)
+    ojod, ostats = orc.Oracle(display_name="standard_hdr_pq" if dt == "u16" else "standard_4k").predict(t, r, dim_order="BCFHW", frames_per_second=50)
+    qs = {}
+    for mode in (1, 2):
+        m = cv.cvvdp(display_name="standard_hdr_pq" if dt == "u16" else "standard_4k")
+        m.fuse_mode = mode
+        jod, stats = m.predict(t, r, dim_order="BCFHW", frames_per_second=50)
+        assert m.fused_levels == (1 if mode == 1 else 0)
+        assert np.all(np.abs(jod.cpu().numpy() - np.asarray(ojod)) <= JOD_TOL)
+        np.testing.assert_allclose(stats["Q_per_ch"], ostats["Q_per_ch"], rtol=2e-4, atol=2e-6)
+        qs[mode] = stats["Q_per_ch"]
+    assert qs[1].shape[0] == 2
+    np.testing.assert_allclose(qs[1], qs[2], rtol=5e-5, atol=5e-7)
+
+
 def test_fused_route_is_a_property_of_the_clip():
     """Blocks and shards of a clip take the same kernels (the decision uses the nominal block): bit-identical for any blocking."""
     import colorvideovdp_amd as cv

@@ -1,5 +1,7 @@
 """Side-by-side intermediates (Gaussian pyramid, per-pixel D) of HIP and oracle for a case dumped by tools/fuzz_shapes.py:
-    python tools/dbg_case.py gpurun_out/fuzz_bad/seedN_caseK.npz"""
+    python tools/dbg_case.py gpurun_out/fuzz_bad/seedN_caseK.npz [frame]
+The intermediates are those of the LAST frame; with a frame index the clip is cut after that frame (the temporal filter is causal,
+so the frame scores as it did in the whole clip)."""
 import sys
 import numpy as np
 import torch
@@ -10,6 +12,8 @@ from oracle import cvvdp_oracle as orc
 
 d = dict(np.load(sys.argv[1]))
 test, ref, fps, disp, pad = d["test"], d["ref"], int(d["fps"]), str(d["display"]), str(d["padding"])
+if len(sys.argv) > 2:
+    test, ref = test[:, :, :int(sys.argv[2]) + 1], ref[:, :, :int(sys.argv[2]) + 1]
 F = test.shape[2]
 m = cv.cvvdp(display_name=disp, temp_padding=pad)
 m.debug_dump = True

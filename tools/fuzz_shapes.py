@@ -1,7 +1,7 @@
 """Randomised shape sweep of the HIP path against the CPU oracle (development aid, run on the GPU box):
     python tools/fuzz_shapes.py [n_cases] [seed]
 Random widths / heights (16..700 x 16..400, all residues mod 16), frame counts, frame rates, displays, padding and heat-map modes;
-every third video case without a heat map forces the fused band kernels (test hook fuse_mode = 1) wherever a level supports them."""
+every second video case without a heat map forces the fused band kernels (test hook fuse_mode = 1) wherever a level supports them."""
 import sys
 import numpy as np
 import torch
@@ -41,7 +41,7 @@ for k in range(n):
     o = orc.Oracle(display_name=disp, temp_padding=pad, heatmap=heat)
     oj, os_ = o.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
     m = cv.cvvdp(display_name=disp, temp_padding=pad, heatmap=heat, block_frames=int(rng.choice([1, 2, 64])))
-    fm = 1 if (F > 1 and not heat and rng.random() < 0.34) else 0
+    fm = 1 if (F > 1 and not heat and rng.random() < 0.5) else 0
     m.fuse_mode = fm
     j, s = m.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
     dq = np.abs(s["Q_per_ch"] - os_["Q_per_ch"]) / (np.abs(os_["Q_per_ch"]) * 2e-4 + 2e-6)

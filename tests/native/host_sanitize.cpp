@@ -216,9 +216,49 @@ static cvvdp_params make_params(std::mt19937& rng) {
   return p;
 }
 
+// Which clips take the band kernels that compute the next level themselves (core.cpp, cvvdp_configure): the rule as a table --
+// plain video scoring only, >= 16 M pixels of a level in the nominal block, more than 1024 level-0 workgroups, even widths.
+static void check_fuse_rule(std::mt19937& rng) {
+  struct Row { int w, h, frames, levels, video, heat, fs, dump, mode, want; };
+  const Row rows[] = {
+      {3840, 2160, 64, 9, 1, 0, 0, 0, 0, 3},   // the bench clip
+      {3840, 2160, 1024, 9, 1, 0, 0, 0, 0, 3}, // configs[3]
+      {7680, 4320, 256, 10, 1, 0, 0, 0, 0, 4}, // 8K: 8294400 x 64 pixels still at level 3
+      {1920, 1080, 64, 8, 1, 0, 0, 0, 0, 2},
+      {1360, 768, 64, 8, 1, 0, 0, 0, 0, 0},    // one round of workgroups: independent levels on three streams win
+      {3840, 2160, 8, 9, 1, 0, 0, 0, 0, 0},    // short clips
+      {3840, 2160, 16, 9, 1, 0, 0, 0, 0, 2},
+      {2566, 1444, 40, 9, 1, 0, 0, 0, 0, 1},   // W % 4 == 2; level 1 is 1283 columns wide (odd)
+      {3841, 2160, 64, 9, 1, 0, 0, 0, 0, 0},   // odd width
+      {3840, 2160, 64, 9, 1, 2, 0, 0, 0, 0},   // heat map, features, per-pixel dump: k_band4's instantiations
+      {3840, 2160, 64, 9, 1, 0, 38, 0, 0, 0},
+      {3840, 2160, 64, 9, 1, 0, 0, 1, 0, 0},
+      {3840, 2160, 1, 9, 0, 0, 0, 0, 0, 0},    // an image
+      {3840, 2160, 64, 9, 1, 0, 0, 0, 2, 0},   // test hook: never / wherever possible
+      {256, 144, 5, 6, 1, 0, 0, 0, 1, 3},      // 256x144 -> 128x72 -> 64x36 (32x18 is below 32 rows)
+  };
+  cvvdp_params p = make_params(rng);
+  cvvdp_handle* h = nullptr;
+  REQUIRE(cvvdp_create(&p, &h) == CVVDP_OK && h, "create failed");
+  REQUIRE(cvvdp_fused_levels(h) == -1, "fused levels of a handle that is not configured");
+  for (const Row& r : rows) {
+    cvvdp_clip c{};
+    c.width = r.w; c.height = r.h; c.batch = 1; c.channels = 3; c.is_video = r.video;
+    c.filter_len = r.video ? 17 : 1; c.total_frames = c.n_frames = r.frames; c.block_frames = r.video ? std::min(64, r.frames) : 1;
+    c.n_levels = r.levels; c.heatmap = r.heat; c.feature_size = r.fs; c.debug_dump = r.dump; c.fuse_mode = r.mode; c.raw_halo = 1;
+    for (int i = 0; i < 4 * CVVDP_MAX_FILTER_LEN; ++i) c.taps[i] = 0.01f * (i % 7);
+    for (auto& v : c.csf_rows) v = 1.0f;
+    snprintf(g_case, sizeof g_case, "fuse rule %dx%dx%d", r.w, r.h, r.frames);
+    REQUIRE(cvvdp_configure(h, &c) == CVVDP_OK, "configure: %s", cvvdp_last_error(h));
+    REQUIRE(cvvdp_fused_levels(h) == r.want, "fused levels %d, expected %d", cvvdp_fused_levels(h), r.want);
+  }
+  cvvdp_destroy(h);
+}
+
 int main(int argc, char** argv) {
   const int n_cases = argc > 1 ? atoi(argv[1]) : 3000;
   std::mt19937 rng(argc > 2 ? (unsigned)atoi(argv[2]) : 1u);
+  check_fuse_rule(rng);
   auto ri = [&](int lo, int hi) { return lo + (int)(rng() % (unsigned)(hi - lo + 1)); };
   long refused = 0, ran = 0;
   float* const fake_ws = reinterpret_cast<float*>(uintptr_t(1) << 40);     // never dereferenced: all checks are address arithmetic

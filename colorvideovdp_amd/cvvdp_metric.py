@@ -304,7 +304,7 @@ class cvvdp(vq_metric):
         return (Q_jod.squeeze(), stats)
 
     # ------------------------------------------------------------------ block planning
-    def _pick_block_frames(self, pix, batch, n_frames, fl, nch, host_resident=False):
+    def _pick_block_frames(self, pix, batch, n_frames, fl, nch, host_resident=False, device_raw=False):
         """Frames per process_block call.  Results do not depend on it (tested).  Larger blocks amortise the
         (fl-1)-frame DKL tail that is written/re-read between blocks (cf. estimate_block_N,
         cvvdp_metric.py:565-594, for the memory model; CVVDP_PIPELINE=1 software-pipelines the blocks on a
@@ -321,7 +321,12 @@ class cvvdp(vq_metric):
             nb = int((budget - fixed) // per_frame)
             # heat maps leave the GPU over PCIe (2-6 B/pixel): 16-frame blocks let the copy of a block overlap the
             # kernels of the next one (4K supra-threshold, 64 frames: 111 ms as one block, 81 ms in blocks of 16)
-            nb = min(nb, 16 if self.do_heatmap else 64)
+            # Raw clips resident in HBM hand every block its fl-1 predecessor frames again (cvvdp_clip.raw_halo): 16 extra frames of
+            # unpack + display model per 64-frame block at 60 fps.  Nothing is staged for them, so their blocks may be as long as the
+            # core's window allows (4K x 256 uint8: 61.0 ms in blocks of 64, 56.5 in one block of 240 + one of 16).  Which kernels
+            # score the clip does not depend on the block (the core decides from a nominal 64-frame block).
+            long_ok = device_raw and not self.do_heatmap and getattr(self, "_feature_out", None) is None
+            nb = min(nb, 16 if self.do_heatmap else (_capi.MAX_WINDOW - fl + 1 if long_ok else 64))
             if host_resident and n_frames > 24:
                 nb = min(nb, 16)   # the upload of block k+1 (side stream, worker thread) hides behind the kernels of block k
         return max(1, min(nb, n_frames, _capi.MAX_WINDOW - fl + 1))
@@ -460,7 +465,7 @@ class cvvdp(vq_metric):
                 taps = np.zeros((4, _capi.MAX_FILTER_LEN), dtype=f32)
                 taps[:, :fl] = F[:, :fl]
                 clip.taps[:] = taps.reshape(-1).tolist()
-                nb = self._pick_block_frames(height * width, B, count, fl, nch, self._host_resident(vs))
+                nb = self._pick_block_frames(height * width, B, count, fl, nch, self._host_resident(vs), bool(clip.raw_halo))
                 clip.filter_len, clip.block_frames = fl, nb
                 self.last_block_frames = nb
             rows = np.zeros((_capi.MAX_LEVELS, 4, _capi.CSF_NODES), dtype=f32)

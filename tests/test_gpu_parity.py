@@ -290,6 +290,26 @@ def test_block_size_invariance_device_resident():
             np.testing.assert_array_equal(qs[0], q)
 
 
+@pytest.mark.parametrize("fuse_mode", [0, 1])
+def test_blocks_longer_than_the_nominal_64_frames(fuse_mode):
+    """Raw clips resident in HBM are scored in blocks of up to 240 frames (cvvdp_metric.py::_pick_block_frames); the core sizes its
+    segments and picks its kernels from a nominal 64-frame block, so a 170-frame clip in one block, in blocks of 100, 64 and 7 gives
+    the same bits -- on the reduce + k_band4 route and on the fused band kernels."""
+    import colorvideovdp_amd as cv
+    t, r = _fuse_clip(256, 144, 170, 11)
+    t, r = torch.as_tensor(t).cuda(), torch.as_tensor(r).cuda()
+    qs, blocks = [], []
+    for nb in (None, 100, 64, 7):
+        m = cv.cvvdp(display_name="standard_fhd", block_frames=nb)
+        m.fuse_mode = fuse_mode
+        _, st = m.predict(t, r, dim_order="BCFHW", frames_per_second=30)
+        qs.append(st["Q_per_ch"]); blocks.append(m.last_block_frames)
+        assert m.fused_levels == (3 if fuse_mode else 0)
+    assert blocks == [170, 100, 64, 7]
+    for q in qs[1:]:
+        np.testing.assert_array_equal(qs[0], q)
+
+
 def test_documented_known_answer():
     """The reference's own KAT (examples/ex_simple_image.py: 'Blur - Quality: 8.514 JOD'), heat map on as in the example."""
     import colorvideovdp_amd as cv
@@ -388,7 +408,7 @@ def test_bench_clip_against_reference(name):
         pytest.fail("this torch build's CPU generator does not reproduce the fixture's synthetic frames (checksum mismatch): the BASELINE-size parity check cannot run -- regenerate tests/golden with oracle/make_goldens_fullsize.py / make_goldens_bench.py")
     m = cv.cvvdp(display_name=disp, heatmap=heat)
     jod, stats = m.predict_video_source(clip)
-    assert m.last_block_frames == min(64, F) or heat is not None       # the geometry the bench runs
+    assert m.last_block_frames == min(240, F) or heat is not None      # the geometry the bench runs (resident raw clips: blocks up to the core's window)
     assert abs(float(jod) - float(g["jod"])) <= JOD_TOL
     np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(stats["rho_band"], g["rho_band"], rtol=1e-12)

@@ -260,6 +260,32 @@ def cpu_baseline(W, H, fps, display, n_frames, frames=None):
                         "0.63 Mpixel/s on 3840x2160 x 4 frames"), float(jod), t, r
 
 
+def device_identity(rank, dev_index):
+    """(rank, device index, uuid / PCI bus id) of the GPU this rank runs on -- gathered over all ranks into `collectives.ranks_seen`."""
+    p = torch.cuda.get_device_properties(dev_index)
+    uuid = getattr(p, "uuid", None)
+    bus = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+    return {"rank": rank, "device_index": dev_index, "uuid": str(uuid) if uuid is not None else None, "pci": bus, "name": p.name,
+            "host": os.uname().nodename}
+
+
+def measured_copy_ceiling():
+    """The best rate a float4 device copy (read + write) reached on a gpurun box: profiles/*ubench_hbm_copy_sweep.txt (tools/ubench/
+    hbm_copy_sweep.hip: plain / nontemporal accesses, 1-8 in flight, grid-stride / chunked, 1 024-16 384 blocks), the newest file.
+    The second denominator SURVEY 8(d) asks for: no read+write stream on these boxes gets closer to the 8 TB/s of the data sheet."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*ubench_hbm_copy_sweep.txt")))
+    if not files:
+        return None
+    best = 0.0
+    for line in open(files[-1]):
+        mt = re.match(r"copy .*?([0-9.]+) TB/s", line)
+        if mt:
+            best = max(best, float(mt.group(1)))
+    return {"GBs": best * 1e3, "source": "profiles/" + os.path.basename(files[-1]) + " (best float4 copy of the sweep)"} if best > 0 else None
+
+
 def lockstep_spinup(step, seconds, world, flag_device, sync=lambda: None, collective=None):
     """Untimed spin-up: run step() for about `seconds`, the SAME number of times on every rank.  Multi-rank, every step() ends in
     a collective (the all-gather of Q_per_ch), so a per-rank clock must not decide when to stop: ranks enter the loop at different
@@ -313,6 +339,10 @@ def main():
     # multi-rank path (shard plan, halo frames, all-gather, rank-0 JSON) can be exercised on a single-GPU box
     dev_index = int(os.environ.get("CVVDP_BENCH_DEVICE", local_rank))
     backend = os.environ.get("CVVDP_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if "CVVDP_BENCH_DEVICE" not in os.environ and have < max(args.gpus, world):
+        # one rank per GPU: fail before any rendezvous, with one line, instead of dying in set_device / inside RCCL on some rank
+        raise SystemExit(f"bench.py: --gpus {max(args.gpus, world)} needs {max(args.gpus, world)} visible GPUs, this node shows {have}")
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     # CVVDP_BENCH_FORCE_DIST=1 (test hook, launched through torch.distributed.run with one process): initialise the process group and run
@@ -325,6 +355,12 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=device)
         else:
             torch.distributed.init_process_group(backend)
+
+    ranks_seen = None
+    if dist_on:
+        # which device every rank really sits on (the SCALE record shows N distinct GPUs, or says that the ranks share one)
+        ranks_seen = [None] * world
+        torch.distributed.all_gather_object(ranks_seen, device_identity(rank, dev_index))
 
     import colorvideovdp_amd as cv
     from colorvideovdp_amd.heatmap_writers import HeatmapFrameMeans
@@ -412,7 +448,8 @@ def main():
     }
     if dist_on:
         out["config"]["collectives"] = {"backend": torch.distributed.get_backend(), "world": world,
-                                        "per_step": "one all-gather of the Q_per_ch shards", "spin_up": "barrier + one broadcast word per step"}
+                                        "per_step": "one all-gather of the Q_per_ch shards", "spin_up": "barrier + one broadcast word per step",
+                                        "ranks_seen": ranks_seen, "distinct_devices": len({r["uuid"] or (r["host"], r["device_index"]) for r in ranks_seen})}
     if golden is not None and gen == "cpu":
         if (clip.checksum_test, clip.checksum_ref) == (int(golden["checksum_test"]), int(golden["checksum_ref"])):
             q, qr = stats["Q_per_ch"].astype(np.float64), golden["Q_per_ch"].astype(np.float64)
@@ -437,6 +474,11 @@ def main():
                               "note": "fewer algorithmic bytes than round 2 (162.6 for f32): fused band kernels read a level once, so the "
                                       "same pixel rate is a smaller fraction" if fused_levels > 0 else "no fused levels for this clip"},
     }
+    ceil = measured_copy_ceiling()
+    if ceil is not None:
+        for k in ("survey_model", "build_algorithmic"):
+            out["path_roofline"][k]["frac_of_measured_copy_per_gpu"] = round(out["path_roofline"][k]["achieved_GBs"] / ceil["GBs"], 4)
+        out["path_roofline"]["measured_copy_ceiling"] = ceil
     if prof is not None:
         ms, n = prof["band_level0"]
         frames_per_launch = count * args.steps / max(n, 1)
@@ -489,6 +531,11 @@ def main():
                                                "achieved_GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4)}
         if ktraffic:
             out["kernel_traffic"] = ktraffic     # counter bytes vs algorithmic bytes of every dominant kernel (profiles/traffic.json)
+            if tj.get("step_valu"):
+                # the other roofline of this path: VALU issue slots (same stamped counter passes, all kernels of one step)
+                out["path_roofline"]["valu_issue"] = tj["step_valu"]
+                if "valu" in out["roofline"]:
+                    out["roofline"]["valu"]["frac_of_issue"] = out["roofline"]["valu"].get("busy")
         tot = sum(v[0] for v in prof.values())
         out["kernel_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in prof.items()}
         out["kernel_ms_per_step"]["sum"] = round(tot / args.steps, 3)

@@ -400,6 +400,9 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
   }
   if (c.heatmap != CVVDP_HEATMAP_NONE && c.batch != 1) return fail(h, CVVDP_E_UNSUPPORTED, "heat maps need batch == 1");
   if (c.feature_size < 0) return fail(h, CVVDP_E_ARG, "feature_size must be >= 0");
+  // features mode runs the FEAT instantiations of the band kernels, which write neither heat-map bands nor the per-pixel D dump
+  if (c.feature_size > 0 && (c.heatmap != CVVDP_HEATMAP_NONE || c.debug_dump))
+    return fail(h, CVVDP_E_UNSUPPORTED, "feature_size > 0 cannot be combined with a heat map or debug_dump");
   if (c.fuse_mode < 0 || c.fuse_mode > 2) return fail(h, CVVDP_E_ARG, "fuse_mode must be 0, 1 or 2");
   h->c = c;
   h->nch = c.is_video ? 4 : 3;
@@ -875,6 +878,7 @@ int cvvdp_debug_buffer(cvvdp_handle* h, int32_t which, int32_t level, void** dev
     case CVVDP_BUF_GPYR: *dev_ptr = h->ws + lv.g_off; *n_floats = (size_t)2 * h->nch * h->items_cap * lv.P; break;
     case CVVDP_BUF_DDUMP:
       if (!h->c.debug_dump && h->c.feature_size <= 0) return fail(h, CVVDP_E_STATE, "debug_dump not enabled");
+      if (lv.feat4 && !h->c.debug_dump) return fail(h, CVVDP_E_STATE, "level %d keeps column sums in features mode, not per-pixel D planes", level);
       *dev_ptr = h->ws + lv.dd_off; *n_floats = (size_t)4 * h->items_cap * lv.P; break;
     case CVVDP_BUF_HEAT:
       if (h->c.heatmap == CVVDP_HEATMAP_NONE) return fail(h, CVVDP_E_STATE, "heat map not enabled");

@@ -326,10 +326,21 @@ class cvvdp(vq_metric):
             # core's window allows (4K x 256 uint8: 61.0 ms in blocks of 64, 56.5 in one block of 240 + one of 16).  Which kernels
             # score the clip does not depend on the block (the core decides from a nominal 64-frame block).
             long_ok = device_raw and not self.do_heatmap and getattr(self, "_feature_out", None) is None
+            if long_ok and nb > 64:
+                # Blocks beyond 64 frames are worth ~7 % and cost up to 4x the workspace: they are sized from an ABSOLUTE share of the
+                # device (30 % of its total memory: 240 frames of 4K on a 288 GB part), not from what happens to be free at call
+                # time -- several processes sharing one GPU would each see the same free memory and run out together.  A workspace
+                # that cannot be had falls back to 64-frame blocks and below (_score_range).
+                nb_abs = int((_total * 0.30 - fixed) // per_frame)
+                nb = max(64, min(nb, nb_abs))
             nb = min(nb, 16 if self.do_heatmap else (_capi.MAX_WINDOW - fl + 1 if long_ok else 64))
             if host_resident and n_frames > 24:
                 nb = min(nb, 16)   # the upload of block k+1 (side stream, worker thread) hides behind the kernels of block k
         return max(1, min(nb, n_frames, _capi.MAX_WINDOW - fl + 1))
+
+    def _alloc_workspace(self, nbytes):
+        """The one device allocation of a call (torch's caching allocator; the core allocates nothing itself)."""
+        return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
 
     def _raw_block(self, vs, a, b):
         """Frames [a,b) of test and reference as BCFHW tensors on the device + dtype code."""
@@ -473,11 +484,24 @@ class cvvdp(vq_metric):
                 rows[bb] = self.csf_table.rows(rho_band[bb])
             clip.csf_rows[:] = rows.reshape(-1).tolist()
             self._clip_cache = (key, clip, fl, F)
-        _capi.check(self._handle, lib.cvvdp_configure(self._handle, ctypes.byref(clip)), "cvvdp_configure")
-        need = lib.cvvdp_workspace_bytes(self._handle)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != self.device:
+        while True:
+            _capi.check(self._handle, lib.cvvdp_configure(self._handle, ctypes.byref(clip)), "cvvdp_configure")
+            need = lib.cvvdp_workspace_bytes(self._handle)
+            if self._ws is not None and self._ws.numel() >= need and self._ws.device == self.device:
+                break
             self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            try:
+                self._ws = self._alloc_workspace(need)
+                break
+            except torch.cuda.OutOfMemoryError:
+                # The block length was sized from the memory that was free a moment ago; somebody else (another rank on this GPU)
+                # may have taken it since.  Results do not depend on the block length: retry with shorter blocks (.., 64, 32, 16, ..).
+                nb_now = int(clip.block_frames)
+                if is_image or self.block_frames is not None or nb_now <= 1:
+                    raise
+                torch.cuda.empty_cache()
+                clip.block_frames = 64 if nb_now > 64 else max(1, nb_now // 2)
+                self.last_block_frames = int(clip.block_frames)
         _capi.check(self._handle, lib.cvvdp_bind_workspace(self._handle, self._ws.data_ptr(), self._ws.numel()), "cvvdp_bind_workspace")
         stream = torch.cuda.current_stream(self.device).cuda_stream
         heatmap = None

@@ -19,10 +19,15 @@
  *     helper streams the handle owns).  No other entry point synchronises.
  *   - the core allocates no device MEMORY: the caller provides one workspace buffer of
  *     cvvdp_workspace_bytes() bytes (so torch's caching allocator stays the only allocator).  It does own a few
- *     HIP objects, created lazily on first use and destroyed with the handle: two non-blocking helper streams
- *     with their fork / join events (the small pyramid levels of images and short blocks run beside level 0 on
- *     them; the caller's stream waits for them by event before anything reads the results) and, while
- *     profiling is enabled, timing events.
+ *     HIP objects, created lazily on first use and destroyed with the handle: up to three non-blocking helper
+ *     streams with their fork / join events -- two for the small pyramid levels of images and short blocks, which
+ *     run beside level 0, and an edge stream on which the border strips of a level run beside its border-free
+ *     strips (fused band kernels; the edge strips of large ragged frames); the caller's stream waits for them
+ *     by event before anything reads the results -- and, while profiling is enabled, timing events.
+ *   - scores do not depend on how a clip is cut into blocks or shards (bit for bit), but the band kernels a level
+ *     runs on depend on what else is asked for: the fused kernels serve plain scoring only, so Q_per_ch / JOD of
+ *     one clip with and without a heat map (or features, or the dump) agree to rounding (observed <= 5e-5 relative
+ *     in Q_per_ch), not bit for bit.  cvvdp_clip.fuse_mode = 2 pins the unfused route for callers who need equality.
  *   - the library reads no environment variable (tuning knobs exist only in a -DCVVDP_DEV_KNOBS build,
  *     cvvdp_build_flags()).
  *   - "item" = one (frame-in-block, batch) pair; item index = frame * batch + b.

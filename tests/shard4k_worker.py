@@ -35,9 +35,9 @@ def main():
         for name in ("test", "ref"):
             mm = np.load(os.path.join(d, name + ".npy"), mmap_mode="r")          # [1,3,F,H,W] uint8
             setattr(clip, name, torch.from_numpy(np.ascontiguousarray(mm[:, :, lo:first + count])).to(dev))
-    # (up to eight ranks share the one GPU of the box here: 64-frame blocks keep their workspaces at 23 GB each -- left to itself
-    # every rank would size its block for the memory it sees free at that moment, 128 frames = 46 GB, eight times over)
-    m = cv.cvvdp(display_name="standard_4k", device=dev, block_frames=64)
+    # (up to eight ranks share the one GPU of the box here and use the product's default block policy: long blocks are sized from an
+    # absolute share of the device, and a workspace that cannot be had any more falls back to 64-frame blocks and below)
+    m = cv.cvvdp(display_name="standard_4k", device=dev)
     m.set_frame_sharding("world")
     jod, stats = m.predict_video_source(clip)
     np.savez(os.path.join(os.environ["SHARD_OUT"], f"rank{rank}.npz"), jod=np.float32(float(jod)), Q_per_ch=stats["Q_per_ch"],

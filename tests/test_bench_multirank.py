@@ -65,3 +65,48 @@ def test_rccl_collectives_run_with_one_rank():
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["config"]["collectives"]["backend"] == "nccl" and d["n_gpus"] == 1 and d["spinup_steps"] >= 1 and 0 < d["jod"] <= 10
+    seen = d["config"]["collectives"]["ranks_seen"]
+    assert len(seen) == 1 and seen[0]["rank"] == 0 and seen[0]["device_index"] == 0 and d["config"]["collectives"]["distinct_devices"] == 1
+
+
+def _device_count():
+    p = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=900)
+    return int(p.stdout.strip() or 0)
+
+
+def test_more_ranks_than_gpus_fails_fast_with_one_line():
+    """`--gpus N` on a node with fewer than N GPUs (and no test hook that pins the ranks to one device) must not reach a rendezvous,
+    set_device on a missing device or RCCL: every rank exits at once with one line that says what is missing."""
+    n = _device_count() + 1
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("CVVDP_BENCH_DEVICE", None); env.pop("CVVDP_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(31900 + (os.getpid() % 1500)), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert p.returncode != 0
+    assert f"needs {n} visible GPUs, this node shows {n - 1}" in p.stdout + p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_two_rank_bench_over_rccl_on_two_gpus():
+    """The real thing, wherever the box has it: two ranks, two GPUs, RCCL (no gloo, no device pinning) -- process group with device_id per
+    rank, the device-tensor branch of sharding.all_gather_frames with world size 2, the MAX all-reduce over real ranks.  Skipped on
+    the one-GPU boxes this build is developed on; a multi-GPU driver box runs it."""
+    if _device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", CVVDP_BENCH_SPINUP_S="0.5")
+    for k in ("CVVDP_BENCH_DEVICE", "CVVDP_BENCH_BACKEND", "CVVDP_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    for workload, extra, frames_total in (("4k64", ["--gen", "gpu"], 128), ("4k1024", ["--frames", "256"], 256)):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(32900 + (os.getpid() % 1500)), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--cpu-frames", "0", "--workload", workload] + extra
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        d = json.loads(lines[0])
+        col = d["config"]["collectives"]
+        assert col["backend"] == "nccl" and d["n_gpus"] == 2 and d["config"]["frames_total"] == frames_total
+        assert col["distinct_devices"] == 2 and sorted(r["device_index"] for r in col["ranks_seen"]) == [0, 1]
+        assert d["value"] > 0 and 0 < d["jod"] <= 10

@@ -310,6 +310,36 @@ def test_blocks_longer_than_the_nominal_64_frames(fuse_mode):
         np.testing.assert_array_equal(qs[0], q)
 
 
+def test_workspace_that_cannot_be_had_falls_back_to_shorter_blocks(monkeypatch):
+    """The block length is sized from the memory seen free a moment before the allocation; when the workspace of a long block
+    cannot be had any more (several ranks on one GPU), the class retries with 64-frame blocks and below instead of failing --
+    with the same bits.  A pinned block_frames is the caller's decision and still raises."""
+    import colorvideovdp_amd as cv
+    t, r = _fuse_clip(256, 144, 170, 11)
+    t, r = torch.as_tensor(t).cuda(), torch.as_tensor(r).cuda()
+    m0 = cv.cvvdp(display_name="standard_fhd")
+    _, s0 = m0.predict(t, r, dim_order="BCFHW", frames_per_second=30)
+    assert m0.last_block_frames == 170
+    need170 = m0._ws.numel()
+    m = cv.cvvdp(display_name="standard_fhd")
+    sizes = []
+
+    def stingy(nbytes, _orig=m._alloc_workspace):
+        sizes.append(nbytes)
+        if nbytes > need170 // 4:                                  # room for a quarter of the 170-frame workspace only
+            raise torch.cuda.OutOfMemoryError("simulated: workspace of %d bytes" % nbytes)
+        return _orig(nbytes)
+
+    monkeypatch.setattr(m, "_alloc_workspace", stingy)
+    _, s1 = m.predict(t, r, dim_order="BCFHW", frames_per_second=30)
+    assert m.last_block_frames == 32 and len(sizes) == 3 and sizes[0] == need170      # 170 -> 64 -> 32
+    np.testing.assert_array_equal(s0["Q_per_ch"], s1["Q_per_ch"])
+    mp = cv.cvvdp(display_name="standard_fhd", block_frames=100)
+    monkeypatch.setattr(mp, "_alloc_workspace", stingy)
+    with pytest.raises(torch.cuda.OutOfMemoryError):
+        mp.predict(t, r, dim_order="BCFHW", frames_per_second=30)
+
+
 def test_documented_known_answer():
     """The reference's own KAT (examples/ex_simple_image.py: 'Blur - Quality: 8.514 JOD'), heat map on as in the example."""
     import colorvideovdp_amd as cv

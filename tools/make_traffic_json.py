@@ -80,6 +80,43 @@ def sq_of(tag, spec):
     return out
 
 
+def step_valu(tag):
+    """All kernels of one 4K x 64 step on the VALU-issue roofline: sum of SQ_ACTIVE_INST_VALU (quad-cycles: x 4 clocks on one of 1 024
+    SIMDs) against the sum of the kernels' shader clocks (SQ_BUSY_CYCLES / 32 SQs), each weighted by its launches per step (= its
+    dispatch count relative to the temporal kernel's, which runs once per step)."""
+    path = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq_counters.txt")
+    if not os.path.isfile(path):
+        return None
+    per = {}
+    for line in open(path):
+        f = line.split()
+        if line.startswith("#"):
+            continue
+        idx = [i for i, x in enumerate(f) if x.startswith("SQ_")]
+        if idx:
+            i = idx[0]
+            per.setdefault((" ".join(f[:i - 1]), int(f[i - 1])), {})[f[i]] = (int(f[i + 1]), float(f[i + 3]))
+    fir = [v for (name, _), v in per.items() if "k_fir" in name and "SQ_BUSY_CYCLES" in v]
+    if not fir:
+        return None
+    n_steps = max(v["SQ_BUSY_CYCLES"][0] for v in fir)
+    valu = clocks = 0.0
+    rows_ = []
+    for (name, wg), v in sorted(per.items()):
+        if "SQ_BUSY_CYCLES" not in v or "SQ_ACTIVE_INST_VALU" not in v:
+            continue
+        per_step = v["SQ_BUSY_CYCLES"][0] / n_steps
+        valu += per_step * v["SQ_ACTIVE_INST_VALU"][1] * 4 / 1024
+        clocks += per_step * v["SQ_BUSY_CYCLES"][1] / 32
+        rows_.append({"kernel": name.replace("void cvvdp::", ""), "workgroups": wg, "launches_per_step": round(per_step, 3),
+                      "valu_busy": round(v["SQ_ACTIVE_INST_VALU"][1] * 4 / 1024 / (v["SQ_BUSY_CYCLES"][1] / 32), 3)})
+    if clocks <= 0:
+        return None
+    return {"valu_clocks_per_simd_per_step": round(valu), "shader_clocks_per_step": round(clocks), "frac_of_issue": round(valu / clocks, 3),
+            "kernels": rows_, "note": "kernels measured one at a time by the counter passes; in the timed step the border-strip launches overlap the others",
+            "source": f"profiles/{tag}_pmc_sq_counters.txt"}
+
+
 def main(tag):
     fe = rows(os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch_size.txt"), "FETCH_SIZE")
     wr = rows(os.path.join(ROOT, "profiles", f"{tag}_pmc_write_size.txt"), "WRITE_SIZE")
@@ -105,7 +142,7 @@ def main(tag):
         stamp["git_head_when_written"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     except OSError:
         pass
-    out = {"workload": "4k64", "dtype": "f32", "stamp": stamp, "kernels": kernels,
+    out = {"workload": "4k64", "dtype": "f32", "stamp": stamp, "kernels": kernels, "step_valu": step_valu(tag),
            "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests of wide coalesced reads as 64 B, MI355X_MICROARCH.md HBM section); "
                          "WRITE_SIZE as reported",
            "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 "

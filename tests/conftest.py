@@ -22,7 +22,7 @@ def _names(pattern):
 
 def golden_cases():
     """Array-input cases made by oracle/make_goldens.py."""
-    return [n for n in _names("*.npz") if n != "setup" and not n.startswith(("yuv", "fullsize", "kat_", "bench_", "deep_", "outputs", "features", "resize_"))]
+    return [n for n in _names("*.npz") if n != "setup" and not n.startswith(("yuv", "fullsize", "kat_", "bench_", "deep_", "outputs", "features", "resize_", "fuzz_"))]
 
 
 def yuv_cases():
@@ -33,6 +33,38 @@ def yuv_cases():
 def resize_cases():
     """.yuv pairs with full_screen_resize, made by oracle/make_goldens_resize.py."""
     return _names("resize_*.npz")
+
+
+def fuzz_golden_cases():
+    """The thin class of the randomised sweep, scored by the real reference (oracle/make_goldens_fuzz.py); inputs are replayed."""
+    return _names("fuzz_*.npz")
+
+
+# ---- observed error margins (VERDICT r3, weak #1 / #2): the generic tolerances of the parity tests are wide enough to hide a drift
+# of the coarse-band Laplacian or a one-bin shift of the heat map's tone curve, so the fixtures that matter carry their own bound =
+# 1.5 x what this build was OBSERVED to do on them (tests/golden/observed_bounds.json, made by tools/make_observed_bounds.py from the
+# values every GPU run of these tests leaves under gpurun_out/observed/).
+_BOUNDS = None
+
+
+def observed_bound(kind, name):
+    global _BOUNDS
+    if _BOUNDS is None:
+        import json
+        path = os.path.join(GOLDEN, "observed_bounds.json")
+        _BOUNDS = json.load(open(path)) if os.path.isfile(path) else {}
+    return (_BOUNDS.get(kind) or {}).get(name)
+
+
+def record_observed(kind, name, values):
+    import json
+    try:
+        d = os.path.join(ROOT, "gpurun_out", "observed")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, f"{kind}__{name}.json"), "w") as f:
+            json.dump(values, f)
+    except OSError:
+        pass
 
 
 def load_golden(name):

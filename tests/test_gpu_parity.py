@@ -32,13 +32,23 @@ def _inputs(g):
     return t, r
 
 
-def _check_heatmap(got, want):
-    got = got.numpy().astype(np.float32)
-    want = want.astype(np.float32)
+def _check_heatmap(got, want, name=None):
+    """Generic bound: <= 1e-3 of the pixels off by more than 2e-3, none by more than 2e-2 (~20 fp16 ulp near 1).  Fixtures with a
+    recorded margin (conftest.observed_bound) are held to 1.5 x what this build was observed to do on them -- a one-bin shift of the
+    tone-map histogram (visualize_diff_map.py:26-35) moves thousands of pixels and cannot hide in the generic bound then."""
+    from conftest import observed_bound, record_observed
+    got = got.numpy().astype(np.float32) if torch.is_tensor(got) else np.asarray(got, dtype=np.float32)
+    want = np.asarray(want).astype(np.float32)
     assert got.shape == want.shape
     d = np.abs(got - want)
-    assert (d > 2e-3).mean() < 1e-3, (d > 2e-3).mean()
-    assert d.max() < 2e-2, d.max()
+    frac, mx, mean = float((d > 2e-3).mean()), float(d.max()), float(d.mean())
+    if name is not None:
+        record_observed("heatmap", name, {"frac_gt_2e-3": frac, "max": mx, "mean": mean})
+    assert frac < 1e-3, frac
+    assert mx < 2e-2, mx
+    b = observed_bound("heatmap", name) if name is not None else None
+    if b is not None:
+        assert frac <= b["frac_gt_2e-3"] and mx <= b["max"] and mean <= b["mean"], (name, frac, mx, mean, b)
 
 
 @pytest.mark.parametrize("name", golden_cases())
@@ -56,7 +66,7 @@ def test_golden(name):
     assert m.get_info_string() == str(g["info"])
     if "heatmap" in g:
         assert stats["heatmap"].dtype == torch.float16 and stats["heatmap"].device.type == "cpu"
-        _check_heatmap(stats["heatmap"], g["heatmap"])
+        _check_heatmap(stats["heatmap"], g["heatmap"], name)
 
 
 @pytest.mark.parametrize("name", ["vid_u8_72x128x12_60_fhd", "vid_u16_67x121x20_30_4k_sym", "vid_u8_135x240x18_60_fhd_raw"])
@@ -351,8 +361,7 @@ def test_documented_known_answer():
     np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
     hm = stats["heatmap"]
     assert tuple(hm.shape) == (1, 3, 1, 683, 1024) and hm.dtype == torch.float16
-    d = np.abs(hm[0, :, 0, ::8, ::8].numpy().astype(np.float32) - g["heatmap_ds"].astype(np.float32))
-    assert (d > 2e-3).mean() < 1e-3 and d.max() <= 2e-2
+    _check_heatmap(hm[0, :, 0, ::8, ::8], g["heatmap_ds"], "kat_wavy_facade")
     # examples/ex_batch_of_images.py: the same pair inside a batch ("BHWC"), next to an identical pair (10 JOD)
     jb, sb = cv.cvvdp(display_name="standard_4k").predict(np.stack([test, ref]), np.stack([ref, ref]), dim_order="BHWC")
     assert tuple(jb.shape) == (2,) and abs(float(jb[0]) - float(g["jod"])) <= JOD_TOL and abs(float(jb[1]) - 10.0) <= 1e-6
@@ -445,8 +454,7 @@ def test_bench_clip_against_reference(name):
     if heat is not None:
         hm = stats["heatmap"]
         assert tuple(hm.shape) == (1, 3, F, H, W) and hm.dtype == torch.float16
-        d = np.abs(hm[0, :, :, ::16, ::16].numpy().astype(np.float32) - g["heatmap_ds"].astype(np.float32))
-        assert (d > 2e-3).mean() < 1e-3 and d.max() <= 2e-2, ((d > 2e-3).mean(), d.max())
+        _check_heatmap(hm[0, :, :, ::16, ::16], g["heatmap_ds"], name)
         assert abs(float(hm.float().mean()) - float(g["heatmap_mean"])) < 2e-4
 
 
@@ -791,8 +799,7 @@ def test_8k_pq_full_temporal_window_heatmap_and_distogram_against_reference():
     hm = stats["heatmap"]
     assert tuple(hm.shape) == (1, 3, F, H, W) and hm.dtype == torch.float16
     keep = [int(k) for k in g["heatmap_frames"]]
-    d = np.abs(hm[0][:, keep, ::16, ::16].numpy().astype(np.float32) - g["heatmap_ds"].astype(np.float32))
-    assert (d > 2e-3).mean() < 1e-3 and d.max() <= 2e-2, ((d > 2e-3).mean(), d.max())
+    _check_heatmap(hm[0][:, keep, ::16, ::16], g["heatmap_ds"], "deep_8k_pq_heat_17f")
     means = np.array([float(hm[0, :, f].float().mean()) for f in range(F)], dtype=np.float32)
     np.testing.assert_allclose(means, g["heatmap_frame_means"], atol=2e-4)
     st = {k: v for k, v in stats.items() if k != "heatmap"}

@@ -10,38 +10,15 @@ import colorvideovdp_amd as cv
 from oracle import cvvdp_oracle as orc
 
 n, seed = (int(sys.argv[1]) if len(sys.argv) > 1 else 30), (int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-rng = np.random.default_rng(seed)
 bad = 0
-for k in range(n):
-    W, H = int(rng.integers(16, 700)), int(rng.integers(16, 400))
-    F = int(rng.choice([1, 1, 2, 3, 7]))
-    fps = 0 if F == 1 else int(rng.choice([24, 30, 50, 60, 120]))
-    disp = str(rng.choice(["standard_fhd", "standard_4k", "standard_hdr_pq"]))
-    pad = str(rng.choice(["replicate", "symmetric"]))
-    heat = str(rng.choice(["none", "none", "raw", "threshold", "supra-threshold"]))
-    heat = None if heat == "none" else heat
-    y, x = np.mgrid[0:H, 0:W]
-    ref = np.stack([np.stack([0.45 + 0.3 * np.sin(2 * np.pi * (3.1 * x / W + f / 9.0) + c) * np.cos(2 * np.pi * 2.3 * y / H) for c in range(3)])
-                    for f in range(F)], axis=1)[None]
-    test = np.clip(ref + 0.05 * rng.standard_normal(ref.shape), 0, 1)
-    dt = str(rng.choice(["u8", "u8", "u16", "f32", "f16"]))
-    B = 1 if heat else int(rng.choice([1, 1, 2]))
-    if B == 2:                                        # a batch with a broadcast reference (video_source.py:247-252)
-        test = np.concatenate([test, np.clip(test + 0.02 * rng.standard_normal(test.shape), 0, 1)], axis=0)
-    if rng.random() < 0.15:                           # luminance-only content
-        test, ref = test[:, :1], ref[:, :1]
-    if dt == "u8":
-        test, ref = np.round(test * 255).astype(np.uint8), np.round(np.clip(ref, 0, 1) * 255).astype(np.uint8)
-    elif dt == "u16":
-        test, ref = np.round(test * 65535).astype(np.uint16), np.round(np.clip(ref, 0, 1) * 65535).astype(np.uint16)
-    elif dt == "f16":
-        test, ref = torch.tensor(test.astype(np.float16)), torch.tensor(np.clip(ref, 0, 1).astype(np.float16))
-    else:
-        test, ref = test.astype(np.float32), np.clip(ref, 0, 1).astype(np.float32)
+from tools import fuzz_cases
+for cs in fuzz_cases.cases(seed, n):
+    k, W, H, F, fps, disp, pad, heat, dt, B = (cs[x] for x in ("k", "W", "H", "F", "fps", "display", "padding", "heatmap", "dtype", "B"))
+    test, ref = fuzz_cases.as_input(cs["test"]), fuzz_cases.as_input(cs["ref"])
     o = orc.Oracle(display_name=disp, temp_padding=pad, heatmap=heat)
     oj, os_ = o.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
-    m = cv.cvvdp(display_name=disp, temp_padding=pad, heatmap=heat, block_frames=int(rng.choice([1, 2, 64])))
-    fm = 1 if (F > 1 and not heat and rng.random() < 0.5) else 0
+    m = cv.cvvdp(display_name=disp, temp_padding=pad, heatmap=heat, block_frames=cs["block_frames"])
+    fm = cs["fuse_mode"]
     m.fuse_mode = fm
     j, s = m.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
     dq = np.abs(s["Q_per_ch"] - os_["Q_per_ch"]) / (np.abs(os_["Q_per_ch"]) * 2e-4 + 2e-6)

@@ -600,7 +600,8 @@ void launch_band4f(const BandArgs& a0, hipStream_t s, hipStream_t s_edge) {
   if (n_edge < a.n_strip) {
     a.strip0 = 1; a.n_strip_l = a.n_strip - n_edge;
     a.per_xcd = (a.n_strip_l * a.n_seg * a.items + 7) / 8;
-    hipLaunchKernelGGL((k_band4f<4, 0>), dim3(8 * a.per_xcd), dim3(256), 0, s, a);
+    if (a.one_wave_layout) hipLaunchKernelGGL((k_band4f<4, 0>), dim3(8 * a.per_xcd), dim3(256), 0, s, a);
+    else launch_band4s(a, s);
   }
 }
 

@@ -1,0 +1,524 @@
+// k_band4f's row march (band4f.hip: the band kernel that computes the coarse level it expands from) divided between TWO KINDS OF WAVES.
+//
+// Why (round 3, profiles/r03_dev_notes.txt 2, 14): with one wave per channel carrying everything -- the 8-row ring
+// of raw rows (64 VGPRs), the 5x5 reduce, expand, contrast, CSF, both blurs (52-register window), masking and pooling -- k_band4f needs
+// 245 VGPRs, runs two waves per SIMD and keeps the VALU pipes 65 % busy: a wave's row is a serial chain of six LDS round trips, two
+// block barriers and ~1150 issue cycles, and one other wave cannot cover it.  The two big pieces of per-lane state never meet:
+//   * FRONT waves (one per channel, waves 0..3): stream the level-l rows (hand-issued loads, the 8-row register ring), reduce row
+//     r+5 (horizontal 5-tap + the running vertical sums), store the completed coarse row as level l+1, roll the 3-row expand window,
+//     write the vertically expanded row r+1 into s_ve, hand the RAW row r+1 to the back through LDS (s_g), and -- one column per
+//     thread -- the luminance terms of row r+1 (1/L_T, 1/L_R, the CSF sensitivities of all channels).
+//   * BACK waves (one per channel, waves 4..7): horizontal expand + Weber contrast + min / difference of row r (from s_ve, s_g,
+//     s_lum, s_S), the horizontal 13-tap blur of the same row (s_m is written and read by the same wave: no block barrier), the
+//     13-row vertical blur window in registers, masking, soft clamp and pooling seven rows behind.
+// Each kind needs <= 128 VGPRs, so a CU holds two 8-wave blocks = four waves per SIMD, and -- waves being dealt to the SIMDs round
+// robin -- every SIMD gets the front and the back wave of one channel of each block: the work per SIMD is what it was, but a wave's
+// chain is half as long and three other waves stand by.  Same two barriers per row; per-row hand-offs are double-buffered by row
+// parity (s_ve, s_g).  LDS: 65.8 KB per block (k_band4f: 50) -- two blocks per CU fit the 160 KB.
+//
+// The arithmetic is k_band4f<4, 0>'s, operation for operation (same FMA chains, same order): the two kernels' partial sums and
+// level-(l+1) planes are bit-identical (tests/test_gpu_parity.py::test_split_band_kernel_matches_the_one_wave_layout).  Only the strips away from the
+// image's left / right border run here (EDGE = 0 of band4f.hip); the border strips keep k_band4f<4, 1 / 2> on the edge stream.
+// Reference arithmetic: lpyr_dec.py:186-239,386-408, cvvdp_metric.py:835-856,945-950,963-971 (see band4.hip / band4f.hip).
+#include <type_traits>
+#include "kernels.h"
+
+namespace cvvdp {
+
+namespace {
+
+constexpr int S_R = 6;             // blur radius
+constexpr int S_BW = 13;
+constexpr int S_HALO = 8;          // aligned halo columns per side
+constexpr int S_SW = 256 - 2 * S_HALO;   // 240 interior columns per strip (= kBand4StripWidth)
+constexpr int S_VE = 136;          // s_ve row: element 4+i = coarse column cb+i (i = 0..127)
+
+struct sf4 { float v[4]; };
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ sf4 s_lds_read4(const float* p) {
+  const float4 q = *reinterpret_cast<const float4*>(p);
+  return sf4{{q.x, q.y, q.z, q.w}};
+}
+__device__ __forceinline__ void s_lds_write4(float* p, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
+  constexpr int NCH = 4, NP = 8;
+  __shared__ __attribute__((aligned(16))) float2 s_ve[2][NP][S_VE / 2];
+  __shared__ __attribute__((aligned(16))) float s_g[2][NP][256];             // raw level-l row handed from the front to the back (by row parity)
+  __shared__ __attribute__((aligned(16))) float s_lum[2][256];               // 1/L_T, 1/L_R
+  __shared__ __attribute__((aligned(16))) float s_S[NCH][256];
+  __shared__ __attribute__((aligned(16))) float s_m[NCH][256];
+  __shared__ __attribute__((aligned(16))) float s_q[NCH][256];
+  __shared__ __attribute__((aligned(16))) float s_d[S_R + 1][NCH][S_SW];     // lane-private ring of |T'-R'| + eps
+  __shared__ __attribute__((aligned(8))) float2 s_lut[NCH][CVVDP_CSF_NODES];
+
+  const int t = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool front = wv < NCH;
+  const int c = wv & (NCH - 1);
+  const int j = t & 63;
+  const int per_xcd = a.per_xcd;
+  const int wu = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);      // XCD-aware work-unit order (band4.hip)
+  if (wu >= a.n_strip_l * a.n_seg * a.items) return;
+  const int sl = wu % a.n_strip_l, seg = (wu / a.n_strip_l) % a.n_seg, item = wu / (a.n_strip_l * a.n_seg);
+  const int strip = a.strip0 + sl;
+  const int H = a.H, W = a.W, Hc = a.Hc, Wc = a.Wc;
+  const int x0 = strip * S_SW;
+  const int fc0 = x0 - S_HALO + 4 * j;
+  const bool interior = j >= 2 && j < 62;
+  const int cb = (x0 - S_HALO) / 2;
+  const int ys = seg * a.seg_h, ye = min(H, ys + a.seg_h);
+  const bool top_seg = seg == 0;
+  // The top segment starts at row 0 (its six reflected rows are filled in by symmetry): the window position of its first row is 6
+  const int r_start = top_seg ? 0 : ys - S_R;
+  const int rend = ye + S_R;
+  const int rreal = min(rend, H);
+
+  for (int i = t; i < NCH * CVVDP_CSF_NODES; i += 512) {
+    const int cc = i / CVVDP_CSF_NODES, k = i - cc * CVVDP_CSF_NODES;
+    const float l0 = a.lut[cc * CVVDP_CSF_NODES + k] * kLog2_10 + fast_log2(a.sens_mul * a.ch_gain[cc] * a.band_mul);
+    const float l1 = a.lut[cc * CVVDP_CSF_NODES + min(k + 1, CVVDP_CSF_NODES - 1)] * kLog2_10 + fast_log2(a.sens_mul * a.ch_gain[cc] * a.band_mul);
+    s_lut[cc][k] = make_float2(l0, l1 - l0);
+  }
+  for (int i = t; i < 2 * NP * (S_VE / 2); i += 512) (&s_ve[0][0][0])[i] = make_float2(0.0f, 0.0f);
+  __syncthreads();
+
+#ifndef S_DIAG_BACK_ONLY
+  if (front) {
+    // =============================================================================================== FRONT: stream, reduce, expand rows
+    const int64_t P = (int64_t)H * W, Pc = (int64_t)Hc * Wc;
+    const int64_t gps = (int64_t)a.items_cap * P, gcps = (int64_t)a.items_cap * Pc;
+    const float* gT = a.g + (int64_t)item * P + (2 * c) * gps;
+    const float* gR = gT + gps;
+    float* g1T = a.g1_out + (int64_t)item * Pc + (2 * c) * gcps;     // level l+1 planes of this channel, written here
+    float* g1R = g1T + gcps;
+    const float e0 = a.kx[0], e1 = a.kx[1], eo = a.kx[2];
+    const float ind_k1 = a.ind_k1, ind_k0 = a.ind_k0;
+    const float rk0 = a.rk[0], rk1 = a.rk[1], rk2 = a.rk[2], rk3 = a.rk[3], rk4 = a.rk[4];
+    // own four columns; the neighbour samples (columns fc0-2, fc0-1 and fc0+4) sit at immediate offsets -8 / +16 from them: the strips
+    // that run here stay clear of the image's left / right border (x0 >= 240, x0 + 248 <= W), so nothing is clamped or masked.  Column
+    // fc0+4 of the last lane may be column W, i.e. the next row's first sample: it only enters coarse columns beyond the blur halo.
+    const uint32_t goff = (uint32_t)fc0 * 4u;
+
+    float4 cA = make_float4(0, 0, 0, 0), cB = cA, cC = cA;          // coarse rows my-1, my, my+1 of this lane's two coarse columns: (T0, T1, R0, R1)
+    float4 rP = cA, rQ = cA;                                        // partial sums of the two coarse rows under construction (older, younger)
+
+    // vertical expand of one fine row from the window -> s_ve[buf] (lpyr_dec.py:229-232); roll: a new coarse row enters first
+    auto coarse_finish = [&](int buf, auto odd_row, bool roll, float4 emitted) {
+      if (roll) { cA = cB; cB = cC; cC = emitted; }
+      const float m0[4] = {cA.x, cA.y, cA.z, cA.w}, m1[4] = {cB.x, cB.y, cB.z, cB.w}, m2[4] = {cC.x, cC.y, cC.z, cC.w};
+      float o[4];
+      if constexpr (decltype(odd_row)::value) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = m1[i] * eo + m2[i] * eo;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = m0[i] * e0 + m1[i] * e1 + m2[i] * e0;
+      }
+      s_ve[buf][2 * c][2 + j] = make_float2(o[0], o[1]);           // coarse columns cb+2j, cb+2j+1 of the test plane ...
+      s_ve[buf][2 * c + 1][2 + j] = make_float2(o[2], o[3]);       // ... and of the reference plane
+    };
+
+    // One level-l row (four own samples + three neighbours per plane) through the horizontal pass, then into the running sums
+    // (band4f.hip consume, EDGE == 0).  a_row: its index (scalar).  Even rows complete coarse row a_row/2 - 1 -> emitted.
+    auto consume = [&](int a_row, auto odd_a, v4f vT, v4f vR, v2f lT, float rT, v2f lR, float rR, float4& emitted) {
+      float4 hr;
+      hr.x = __builtin_fmaf(vT.z, rk4, __builtin_fmaf(vT.y, rk3, __builtin_fmaf(vT.x, rk2, __builtin_fmaf(lT.y, rk1, lT.x * rk0))));
+      hr.y = __builtin_fmaf(rT, rk4, __builtin_fmaf(vT.w, rk3, __builtin_fmaf(vT.z, rk2, __builtin_fmaf(vT.y, rk1, vT.x * rk0))));
+      hr.z = __builtin_fmaf(vR.z, rk4, __builtin_fmaf(vR.y, rk3, __builtin_fmaf(vR.x, rk2, __builtin_fmaf(lR.y, rk1, lR.x * rk0))));
+      hr.w = __builtin_fmaf(rR, rk4, __builtin_fmaf(vR.w, rk3, __builtin_fmaf(vR.z, rk2, __builtin_fmaf(vR.y, rk1, vR.x * rk0))));
+      const bool ok = a_row >= 0 && a_row < H;
+      const bool border = a_row <= 1 || a_row >= H - 2;               // (scalar)
+      auto axpy = [](float4& y, const float4& x, float w) {
+        y.x = __builtin_fmaf(x.x, w, y.x); y.y = __builtin_fmaf(x.y, w, y.y); y.z = __builtin_fmaf(x.z, w, y.z); y.w = __builtin_fmaf(x.w, w, y.w);
+      };
+      if constexpr (decltype(odd_a)::value) {
+        if (ok) {
+          axpy(rP, hr, rk3);
+          axpy(rQ, hr, rk1);
+          if (border) {
+            if (a_row == 1) axpy(rP, hr, rk0);                        // coarse row 0: + k0 * row 1
+            if (!(H & 1) && a_row == H - 1) axpy(rP, hr, rk4);        // H even, last coarse row: + k4 * row H-1
+            if ((H & 1) && a_row == H - 2) axpy(rQ, hr, rk4);         // H odd,  last coarse row: + k4 * row H-2
+          }
+        }
+      } else {
+        if (ok) {
+          axpy(rP, hr, rk4);
+          axpy(rQ, hr, rk2);
+          if (border) {
+            if (a_row == 0) axpy(rQ, hr, rk1);                        // coarse row 0: + k1 * row 0
+            if ((H & 1) && a_row == H - 1) axpy(rQ, hr, rk3);         // H odd, last coarse row: + k3 * row H-1
+          }
+        }
+        emitted = rP;
+        rP = rQ;
+        rQ = ok ? make_float4(hr.x * rk0, hr.y * rk0, hr.z * rk0, hr.w * rk0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const int m1 = (a_row >> 1) - 1;                             // the coarse row just completed
+        if (m1 > Hc - 1) emitted = cC;                               // below the last coarse row: its replica (the expand clamps)
+        // level l+1 belongs to the lanes that own its columns (interior of the strip) in the segment that owns its rows
+        const int own_end = seg == a.n_seg - 1 ? Hc : (ye >> 1);
+        if (interior && m1 >= (ys >> 1) && m1 < own_end) {
+          const int64_t o = (int64_t)m1 * Wc + (cb + 2 * j);
+          __builtin_nontemporal_store(v2f{emitted.x, emitted.y}, reinterpret_cast<v2f*>(g1T + o));
+          __builtin_nontemporal_store(v2f{emitted.z, emitted.w}, reinterpret_cast<v2f*>(g1R + o));
+        }
+      }
+    };
+
+    // per-column luminance terms of one row, shared by all channels (band4.hip lum_prep): front thread t = column t
+    const bool lodd = t & 1;
+    const float lwa = lodd ? 0.0f : e0, lwb = lodd ? eo : e1, lwc = lodd ? eo : e0;
+    auto lum_prep = [&](int buf) {
+      const float* yT = reinterpret_cast<const float*>(&s_ve[buf][0][0]);
+      const float* yR = reinterpret_cast<const float*>(&s_ve[buf][1][0]);
+      const int col = t;
+      const int e = 4 + (col >> 1);
+      const float eyT = yT[e - 1] * lwa + yT[e] * lwb + yT[e + 1] * lwc;
+      const float eyR = yR[e - 1] * lwa + yR[e] * lwb + yR[e + 1] * lwc;
+      const float Lt = fmaxf(eyT, 0.01f), Lr = fmaxf(eyR, 0.01f);              // lpyr_dec.py:394
+      float ind = fast_log2(Lr) * ind_k1 - ind_k0;
+      ind = __builtin_amdgcn_fmed3f(ind, 0.0f, (float)(CVVDP_CSF_NODES - 1));  // clamp (interp.py:93)
+      const int i0 = (int)ind;
+      const float fr = __builtin_amdgcn_fractf(ind);
+      s_lum[0][col] = fast_rcp(Lt);
+      s_lum[1][col] = fast_rcp(Lr);
+#pragma unroll
+      for (int cc = 0; cc < NCH; ++cc) {                                       // csf.py:49, cvvdp_metric.py:709,:836
+        const float2 ln = s_lut[cc][i0];
+        s_S[cc][col] = fast_exp2(ln.x + ln.y * fr);
+      }
+    };
+
+    // ---- STREAM LOADS (band4f.hip): issued from inline assembly, waited for with one exact count per step.
+    // The ring holds SIX rows (k_band4f: eight): row s+1 leaves for the back in phase 1 of step s, before row s+7 is requested into
+    // the same slot in phase 2 (the barrier between them has drained the LDS write), and the neighbour samples need one set, not two
+    // (row s+6's are requested after row s+5's were used).
+    //   phase 2 of step s:  neighbour samples of row s+6 (4 loads), rows s+7 of the two planes (2 loads) -> ring slot (s+7) % 6 = (s+1) % 6
+    //   start of step s:    needs ring slot (s+5) % 6 and the neighbour samples of row s+5; younger: the 2 row loads of step s-1 -> vmcnt(2)
+    v4f ringT[6], ringR[6];
+    v2f nbLT, nbLR;
+    float nbRT, nbRR;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { ringT[i] = 0.0f; ringR[i] = 0.0f; }
+    nbLT = 0.0f; nbLR = 0.0f; nbRT = 0.0f; nbRR = 0.0f;
+#ifdef CVVDP_SAFE_LOADS
+    // `make safe`: the same kernel with ordinary loads the compiler tracks and waits for itself (the dynamic check of the hand-managed ones)
+#define S_ROWPTR(plane, row, off) (reinterpret_cast<const char*>((plane) + (int64_t)(row) * W) + (off))
+#define S_LOAD4(dst, off, plane, row) dst = *reinterpret_cast<const v4f*>(S_ROWPTR(plane, row, off))
+#define S_LOADL(dst, off, plane, row) dst = *reinterpret_cast<const v2f*>(S_ROWPTR(plane, row, off) - 8)
+#define S_LOADR(dst, off, plane, row) dst = *reinterpret_cast<const float*>(S_ROWPTR(plane, row, off) + 16)
+#define S_WAIT2(...) do { } while (0)
+#define S_DRAIN() do { } while (0)
+#else
+#define S_LOAD4(dst, off, plane, row) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W))
+#define S_LOADL(dst, off, plane, row) asm volatile("global_load_dwordx2 %0, %1, %2 offset:-8" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W))
+#define S_LOADR(dst, off, plane, row) asm volatile("global_load_dword %0, %1, %2 offset:16" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W))
+#define S_WAIT2(a0, a1, a2, a3, a4, a5) asm volatile("s_waitcnt vmcnt(2)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5))
+    // (the drain names every register a load may still be heading for: without that use the compiler sees the last rows' loads as dead
+    // values and hands their registers to temporaries while the loads are in flight)
+#define S_DRAIN() asm volatile("s_waitcnt vmcnt(0)" : "+v"(ringT[0]), "+v"(ringT[1]), "+v"(ringT[2]), "+v"(ringT[3]), "+v"(ringT[4]), "+v"(ringT[5]), \
+                               "+v"(ringR[0]), "+v"(ringR[1]), "+v"(ringR[2]), "+v"(ringR[3]), "+v"(ringR[4]), "+v"(ringR[5]), \
+                               "+v"(nbLT), "+v"(nbLR), "+v"(nbRT), "+v"(nbRR))
+#endif
+    auto rowc = [&](int r) { return min(max(r, 0), H - 1); };       // rows outside the image: any valid row (their weight is 0)
+
+    // ---- prologue: rows r_start-4 .. r_start+4 prime the reduce (three complete coarse rows in the window, two partial ones),
+    // rows r_start .. r_start+4 stay in ring slots 0 .. 4, the rows after them are requested
+    {
+      auto ld4 = [&](const float* plane, int r) -> v4f {
+        return *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(plane + (int64_t)rowc(r) * W) + goff);
+      };
+      auto ld2 = [&](const float* plane, int r) -> v2f { return *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(plane + (int64_t)rowc(r) * W) + goff - 8); };
+      auto ld1 = [&](const float* plane, int r) -> float { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane + (int64_t)rowc(r) * W) + goff + 16); };
+      float4 em = cC;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int ar = r_start - 4 + i;                               // r_start is even: i even <-> row even
+        const v4f vT = ld4(gT, ar), vR = ld4(gR, ar);
+        const v2f lT = ld2(gT, ar), lR = ld2(gR, ar);
+        const float rT = ld1(gT, ar), rR = ld1(gR, ar);
+        if (i == 4) {                                                 // raw row r_start goes straight to the back
+          *reinterpret_cast<v4f*>(&s_g[0][2 * c][4 * j]) = vT;
+          *reinterpret_cast<v4f*>(&s_g[0][2 * c + 1][4 * j]) = vR;
+        }
+        if (i > 4) { ringT[i - 4] = vT; ringR[i - 4] = vR; }           // rows r_start+1 .. r_start+4 in slots 1 .. 4 (the ring holds the rows as loaded)
+        if (i & 1) {
+          consume(ar, std::true_type{}, vT, vR, lT, rT, lR, rR, em);
+        } else {
+          consume(ar, std::false_type{}, vT, vR, lT, rT, lR, rR, em);
+          cA = cB; cB = cC; cC = em;
+        }
+      }
+      if (r_start == 0) cA = cB;                                      // coarse row -1 does not exist: the expand clamps to row 0
+      S_LOAD4(ringT[5], goff, gT, rowc(r_start + 5));
+      S_LOAD4(ringR[5], goff, gR, rowc(r_start + 5));
+      S_LOADL(nbLT, goff, gT, rowc(r_start + 5));
+      S_LOADR(nbRT, goff, gT, rowc(r_start + 5));
+      S_LOADL(nbLR, goff, gR, rowc(r_start + 5));
+      S_LOADR(nbRR, goff, gR, rowc(r_start + 5));
+      S_LOAD4(ringT[0], goff, gT, rowc(r_start + 6));
+      S_LOAD4(ringR[0], goff, gR, rowc(r_start + 6));
+      coarse_finish(0, std::false_type{}, false, cC);                 // vertical expand of row r_start (even)
+    }
+    __syncthreads();
+    lum_prep(0);
+    __syncthreads();
+
+    // one real row r (0 <= r < H); U = (r - r_start) mod 6 = its ring slot
+    auto step = [&](int r, auto u_) {
+      constexpr int U = decltype(u_)::value;
+      constexpr bool ODD = (U & 1) != 0;
+      constexpr int S5 = (U + 5) % 6, S1 = (U + 1) % 6;
+      (void)&ringT; (void)&ringR; (void)&nbLT; (void)&nbLR; (void)&nbRT; (void)&nbRR; (void)&goff; (void)&gT; (void)&gR; (void)&W;
+      S_WAIT2(ringT[S5], ringR[S5], nbLT, nbLR, nbRT, nbRR);
+      // ================= phase 1: level-l row r+5 into the reduce; an even row completes a coarse row, which rolls the window for row r+1
+      float4 emitted = cC;
+      consume(r + 5, std::integral_constant<bool, !ODD>{}, ringT[S5], ringR[S5], nbLT, nbRT, nbLR, nbRR, emitted);
+      coarse_finish(ODD ? 0 : 1, std::integral_constant<bool, !ODD>{}, ODD, emitted);   // vertical expand of row r+1
+      *reinterpret_cast<v4f*>(&s_g[ODD ? 0 : 1][2 * c][4 * j]) = ringT[S1];             // raw row r+1 for the back (arrived four steps ago)
+      *reinterpret_cast<v4f*>(&s_g[ODD ? 0 : 1][2 * c + 1][4 * j]) = ringR[S1];
+      __syncthreads();
+      // ================= phase 2
+      {
+        const int r6 = rowc(r + 6), r7 = rowc(r + 7);
+        S_LOADL(nbLT, goff, gT, r6);
+        S_LOADR(nbRT, goff, gT, r6);
+        S_LOADL(nbLR, goff, gR, r6);
+        S_LOADR(nbRR, goff, gR, r6);
+        S_LOAD4(ringT[S1], goff, gT, r7);                             // (r + 7) % 6 == (r + 1) % 6: the slot that has just been handed on
+        S_LOAD4(ringR[S1], goff, gR, r7);
+      }
+      lum_prep(ODD ? 0 : 1);
+      __syncthreads();
+    };
+
+    // Whole groups of six rows without an exit inside (a `break` in the unrolled body makes the structuriser route every exit through
+    // the loop's latch, and the layout-order ISA check -- tools/check_band4_isa.py -- then sees paths "exit -> latch -> header" that no
+    // execution takes); the last 0..5 rows of the march follow as straight-line code.
+    int r = r_start;
+    for (; r + 6 <= rreal; r += 6) {
+      step(r, std::integral_constant<int, 0>{});
+      step(r + 1, std::integral_constant<int, 1>{});
+      step(r + 2, std::integral_constant<int, 2>{});
+      step(r + 3, std::integral_constant<int, 3>{});
+      step(r + 4, std::integral_constant<int, 4>{});
+      step(r + 5, std::integral_constant<int, 5>{});
+    }
+    if (r < rreal) {
+      step(r, std::integral_constant<int, 0>{});
+      if (r + 1 < rreal) {
+        step(r + 1, std::integral_constant<int, 1>{});
+        if (r + 2 < rreal) {
+          step(r + 2, std::integral_constant<int, 2>{});
+          if (r + 3 < rreal) {
+            step(r + 3, std::integral_constant<int, 3>{});
+            if (r + 4 < rreal) step(r + 4, std::integral_constant<int, 4>{});
+          }
+        }
+      }
+    }
+    S_DRAIN();
+    for (r = rreal; r < rend; ++r) {          // reflected rows below the image: the back works from its window, the front only keeps step
+      __syncthreads();
+      __syncthreads();
+    }
+#undef S_LOAD4
+#undef S_LOADL
+#undef S_LOADR
+#undef S_WAIT2
+#undef S_DRAIN
+#ifdef CVVDP_SAFE_LOADS
+#undef S_ROWPTR
+#endif
+  }
+#endif
+#ifndef S_DIAG_FRONT_ONLY
+  if (!front) {
+    // =============================================================================================== BACK: contrast, blurs, masking, pooling
+    const float e0 = a.kx[0], e1 = a.kx[1], eo = a.kx[2];
+    const float mask_p = a.mask_p, eps_p = a.eps_p;
+    const float qc = a.q[c];
+    const float xw0 = a.xw[0 * 4 + c], xw1 = a.xw[1 * 4 + c], xw2 = a.xw[2 * 4 + c], xw3 = a.xw[3 * 4 + c];
+    const float m1c = a.m1[c];
+    const float inv_dmax = a.inv_dmax;
+
+    // horizontal half of the expand for this lane's 4 columns from 4 coarse values (lpyr_dec.py:234-237)
+    auto expand4 = [&](const float2* row, float (&ex)[4]) {
+      const float2 p0 = row[j + 1];
+      const float2 p1 = row[j + 2];
+      const float2 p2 = row[j + 3];
+      const float A = p0.y, B = p1.x, C = p1.y, D = p2.x;
+      ex[0] = A * e0 + B * e1 + C * e0;
+      ex[1] = B * eo + C * eo;
+      ex[2] = B * e0 + C * e1 + D * e0;
+      ex[3] = C * eo + D * eo;
+    };
+
+    // vertical-blur window (band4.hip): slot s of column i = one horizontally blurred row, weights rotate instead of the data
+    typedef float v32f __attribute__((ext_vector_type(32)));
+    v32f winA = 0.0f, winB = 0.0f;
+    const v2f E0 = {a.blur_h[0], a.blur_h[1]}, E1 = {a.blur_h[2], a.blur_h[3]}, E2 = {a.blur_h[4], a.blur_h[5]}, E3 = {a.blur_h[6], a.blur_h[5]};
+    const v2f O0 = {a.blur_h[1], a.blur_h[2]}, O1 = {a.blur_h[3], a.blur_h[4]}, O2 = {a.blur_h[5], a.blur_h[6]};
+#define S_SWAP(p) __builtin_shufflevector(p, p, 1, 0)
+    const v2f be[6] = {E0, E1, E2, E3, S_SWAP(O1), S_SWAP(O0)};
+    const v2f bo[6] = {O0, O1, O2, S_SWAP(E2), S_SWAP(E1), S_SWAP(E0)};
+#undef S_SWAP
+    const float b0 = a.blur_h[0], b12 = a.blur_h[0];
+    const int n0 = top_seg ? S_R : 0;
+    float wr[S_BW];
+#pragma unroll
+    for (int k = 0; k < S_BW; ++k) wr[k] = a.blur[(k + 2 * S_BW - 1 - n0) % S_BW];
+    float acc = 0.0f;
+
+    // pooling stage of centre row y (band4.hip stage3c)
+    auto stage3c = [&](int k7) {
+      const sf4 q0 = s_lds_read4(&s_q[0][4 * j]), q1 = s_lds_read4(&s_q[1][4 * j]), q2 = s_lds_read4(&s_q[2][4 * j]);
+      const sf4 q3 = s_lds_read4(&s_q[3][4 * j]);
+      const sf4 d = s_lds_read4(&s_d[k7][c][4 * j - S_HALO]);
+      float De[4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const v2f Q0 = {q0.v[2 * h], q0.v[2 * h + 1]}, Q1 = {q1.v[2 * h], q1.v[2 * h + 1]}, Q2 = {q2.v[2 * h], q2.v[2 * h + 1]}, Q3 = {q3.v[2 * h], q3.v[2 * h + 1]};
+        const v2f M1 = Q3 * xw3 + (Q2 * xw2 + (Q1 * xw1 + (Q0 * xw0 + m1c)));
+        const v2f X = {fast_pow(d.v[2 * h], mask_p) - eps_p, fast_pow(d.v[2 * h + 1], mask_p) - eps_p};
+        const v2f T = X * inv_dmax + M1;
+        const float r0 = fast_rcp(T.x), r1 = fast_rcp(T.y);
+        De[2 * h] = __builtin_fmaf(X.x, r0, kEps); De[2 * h + 1] = __builtin_fmaf(X.y, r1, kEps);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_fmaf(De[i], De[i], acc);   // sum of (D + eps)^2; k_finalize takes the eps^2 off
+    };
+    // vertical 13-tap blur of the window -> Mq = (blur + eps)^q -> s_q; then the weights rotate
+    auto vblur = [&](int yc) {
+      if (interior && yc >= ys) {
+        v2f va = kEps, vb = kEps;
+#pragma unroll
+        for (int sdx = 0; sdx < S_BW; ++sdx) {
+          const v2f wa = {winA[2 * sdx], winA[2 * sdx + 1]}, wb = {winB[2 * sdx], winB[2 * sdx + 1]};
+          const v2f ww = {wr[sdx], wr[sdx]};
+          va += ww * wa; vb += ww * wb;
+        }
+        const float v[4] = {va.x, va.y, vb.x, vb.y};
+        float Mq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Mq[i] = fast_pow(v[i], qc);
+        s_lds_write4(&s_q[c][4 * j], Mq);
+      }
+      const float last = wr[S_BW - 1];
+#pragma unroll
+      for (int k = S_BW - 1; k > 0; --k) wr[k] = wr[k - 1];
+      wr[0] = last;
+    };
+
+    __syncthreads();        // (front: prologue -> s_ve[0], s_g[0])
+    __syncthreads();        // (front: luminance terms of row r_start)
+
+    int slot = n0, k7 = 0;
+    // one real row r (0 <= r < H)
+    auto step = [&](int r, auto odd_) {
+      constexpr bool ODD = decltype(odd_)::value;
+      // ================= phase 1
+      const int yprev = r - 1 - S_R;
+      if (interior && yprev >= ys) stage3c(k7);
+      {
+        float exT[4], exR[4];
+        expand4(s_ve[ODD][2 * c], exT);
+        expand4(s_ve[ODD][2 * c + 1], exR);
+        const sf4 rLt = s_lds_read4(&s_lum[0][4 * j]), rLr = s_lds_read4(&s_lum[1][4 * j]);
+        const sf4 Sv = s_lds_read4(&s_S[c][4 * j]);
+        const sf4 gt = s_lds_read4(&s_g[ODD][2 * c][4 * j]), gr = s_lds_read4(&s_g[ODD][2 * c + 1][4 * j]);
+        float m[4], d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float S = Sv.v[i];
+          const float ct = fminf((gt.v[i] - exT[i]) * rLt.v[i], 1000.0f);            // lpyr_dec.py:402 (band gain :66 is in S)
+          const float cr = fminf((gr.v[i] - exR[i]) * rLr.v[i], 1000.0f);
+          m[i] = fminf(fabsf(ct), fabsf(cr)) * S;                                  // min(|T'|,|R'|), T' = ct*S (cvvdp_metric.py:845)
+          d[i] = fabsf(ct - cr) * S + kEps;                                        // |T'-R'| + eps (:855, safe_pow)
+        }
+        s_lds_write4(&s_m[c][4 * j], m);
+        if (interior) s_lds_write4(&s_d[k7][c][4 * j - S_HALO], d);
+      }
+      // s_m[c] is this wave's own row: its LDS operations execute in order, the horizontal blur needs no block barrier
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (interior) {
+        const v4f* row = reinterpret_cast<const v4f*>(&s_m[c][4 * j - 8]);
+        const v4f a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3], a4 = row[4];
+        const v2f xp[10] = {a0.xy, a0.zw, a1.xy, a1.zw, a2.xy, a2.zw, a3.xy, a3.zw, a4.xy, a4.zw};
+        float h[4];
+        {
+          v2f s0 = be[0] * xp[1], s1 = bo[0] * xp[2], s2 = be[0] * xp[2], s3 = bo[0] * xp[3];
+#pragma unroll
+          for (int mm = 1; mm < 6; ++mm) {
+            s0 += be[mm] * xp[1 + mm]; s1 += bo[mm] * xp[2 + mm]; s2 += be[mm] * xp[2 + mm]; s3 += bo[mm] * xp[3 + mm];
+          }
+          h[0] = (s0.x + b12 * xp[7].x) + s0.y;
+          h[1] = (s1.x + b0 * xp[1].y) + s1.y;
+          h[2] = (s2.x + b12 * xp[8].x) + s2.y;
+          h[3] = (s3.x + b0 * xp[2].y) + s3.y;
+        }
+        winA[2 * slot] = h[0]; winA[2 * slot + 1] = h[1]; winB[2 * slot] = h[2]; winB[2 * slot + 1] = h[3];
+        if (top_seg && r >= 1 && r <= S_R) {              // rows 1..6 of the image are also its reflected rows -1..-6 (window slots 5..0)
+          const int ms = S_R - r;
+          winA[2 * ms] = h[0]; winA[2 * ms + 1] = h[1]; winB[2 * ms] = h[2]; winB[2 * ms + 1] = h[3];
+        }
+      }
+      __syncthreads();
+      // ================= phase 2
+      vblur(r - S_R);
+      slot = slot == S_BW - 1 ? 0 : slot + 1;
+      k7 = k7 == S_R ? 0 : k7 + 1;
+      __syncthreads();
+    };
+    // one reflected row below the image (r >= H): its horizontally blurred row is that of row 2(H-1) - r, still in the window
+    auto tail_step = [&](int r) {
+      const int yprev = r - 1 - S_R;
+      if (interior && yprev >= ys) stage3c(k7);
+      __syncthreads();
+      if (interior) {
+        const int back = 2 * (r - (H - 1));                           // 2, 4, .. 12 rows back
+        const int src = slot >= back ? slot - back : slot - back + S_BW;
+        const float h0 = winA[2 * src], h1 = winA[2 * src + 1], h2 = winB[2 * src], h3 = winB[2 * src + 1];
+        winA[2 * slot] = h0; winA[2 * slot + 1] = h1; winB[2 * slot] = h2; winB[2 * slot + 1] = h3;
+      }
+      vblur(r - S_R);
+      slot = slot == S_BW - 1 ? 0 : slot + 1;
+      k7 = k7 == S_R ? 0 : k7 + 1;
+      __syncthreads();
+    };
+
+    int r = r_start;                                       // (even)
+    for (; r < rreal; r += 2) {
+      step(r, std::false_type{});
+      if (r + 1 >= rreal) break;
+      step(r + 1, std::true_type{});
+    }
+    for (r = rreal; r < rend; ++r) tail_step(r);
+    // ---- epilogue: pooling stage of the last centre row
+    if (interior && (ye - 1) >= ys) stage3c(k7);
+
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (j == 0) {
+      const int nblk = a.n_strip * a.n_seg;
+      a.partial[((int64_t)item * nblk + (seg * a.n_strip + strip)) * 4 + c] = acc;
+    }
+  }
+#endif
+}
+
+// the strips away from the image's left / right border of a fused level (launch_band4f deals them: strip0 .. strip0 + n_strip_l - 1)
+void launch_band4s(const BandArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_band4s, dim3(8 * a.per_xcd), dim3(512), 0, s, a);
+}
+
+}  // namespace cvvdp

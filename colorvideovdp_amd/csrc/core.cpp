@@ -276,6 +276,7 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
     if (fused) {
       a.g1_out = gbase(h, l + 1, set);
       for (int i = 0; i < 5; ++i) a.rk[i] = K[i];
+      a.one_wave_layout = h->c.band_layout == 1;
       launch_band4f(a, s, s_edge);
     } else if (lv.vec4) {
       launch_band4(a, lv.split_edge, s, s_edge);
@@ -404,6 +405,7 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
   if (c.feature_size > 0 && (c.heatmap != CVVDP_HEATMAP_NONE || c.debug_dump))
     return fail(h, CVVDP_E_UNSUPPORTED, "feature_size > 0 cannot be combined with a heat map or debug_dump");
   if (c.fuse_mode < 0 || c.fuse_mode > 2) return fail(h, CVVDP_E_ARG, "fuse_mode must be 0, 1 or 2");
+  if (c.band_layout < 0 || c.band_layout > 1) return fail(h, CVVDP_E_ARG, "band_layout must be 0 or 1");
   h->c = c;
   h->nch = c.is_video ? 4 : 3;
   h->L = c.n_levels;

@@ -98,6 +98,7 @@ class cvvdp(vq_metric):
         self._ws = None
         self._shard = None
         self.debug_dump = False
+        self.band_layout = 0          # cvvdp_clip.band_layout: 0 = front / back waves on fused levels (normal use); 1 = one wave per channel (A/B switch, same bits)
         self.fuse_mode = 0            # cvvdp_clip.fuse_mode: 0 = the core decides (normal use); 1 / 2 = fused band kernels everywhere / nowhere (tests)
         self.set_display_model(display_name, display_photometry=display_photometry, display_geometry=display_geometry,
                                config_paths=config_paths)
@@ -445,7 +446,7 @@ class cvvdp(vq_metric):
         # The clip description (temporal taps, CSF rows per band, block size) depends only on the geometry: repeated
         # calls on clips of the same shape reuse it, so the first kernel is not held back by ~0.4 ms of host set-up.
         key = (height, width, N_total, first, count, B, C, is_image, None if is_image else float(vs.get_frames_per_second()), self.heatmap,
-               bool(self.debug_dump), int(self.fuse_mode), self.block_frames, self.gpu_mem, float(self.pix_per_deg), self._cfg_version, prefiltered, getattr(self, "_feature_out", None) is not None,
+               bool(self.debug_dump), int(self.fuse_mode), int(self.band_layout), self.block_frames, self.gpu_mem, float(self.pix_per_deg), self._cfg_version, prefiltered, getattr(self, "_feature_out", None) is not None,
                self._host_resident(vs))
         cached = getattr(self, "_clip_cache", None)
         if cached is not None and cached[0] == key:
@@ -461,6 +462,7 @@ class cvvdp(vq_metric):
             clip.heatmap = _capi.HEATMAP[self.heatmap]
             clip.debug_dump = int(self.debug_dump)
             clip.fuse_mode = int(self.fuse_mode)
+            clip.band_layout = int(self.band_layout)
             clip.feature_size = int(math.ceil(self.pix_per_deg)) if getattr(self, "_feature_out", None) is not None else 0   # cvvdp_ml_metric.py:353
             # device-resident clips: later blocks re-read their fl-1 predecessor frames (like a shard's halo) instead of
             # a DKL tail written by the previous block: 3.2 GB less HBM traffic per 64-frame 4K block

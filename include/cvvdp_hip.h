@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CVVDP_ABI_VERSION 10
+#define CVVDP_ABI_VERSION 11
 #define CVVDP_MAX_FILTER_LEN 65 /* 0.25 s at up to 256 fps, cvvdp_metric.py:1059 */
 #define CVVDP_MAX_LEVELS 16
 #define CVVDP_MAX_WINDOW 256    /* filter_len - 1 + frames per block */
@@ -122,6 +122,9 @@ typedef struct cvvdp_clip {
                                    next level itself (no reduce pass for them; clips whose blocks fill the GPU several times over);
                                    1: every level that supports it, whatever the size of the clip; 2: none.  1 / 2 are test hooks: the
                                    two routes agree to rounding, not bit for bit */
+  int32_t band_layout;          /* how a fused level's band kernel divides its work between waves.  0 (normal use): front / back waves
+                                   (band4s.hip: 8 waves per block, four per SIMD); 1: one wave per channel (round 3's k_band4f everywhere,
+                                   two per SIMD).  Same arithmetic, bit-identical results: 1 is the A/B switch of tests and benchmarks */
   float taps[4 * CVVDP_MAX_FILTER_LEN];                             /* F[c][k], not flipped */
   float csf_rows[CVVDP_MAX_LEVELS * 4 * CVVDP_CSF_NODES];           /* [band][ch][node] log10 S */
 } cvvdp_clip;

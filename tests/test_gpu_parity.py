@@ -959,3 +959,34 @@ def test_fused_route_is_a_property_of_the_clip():
         qs.append(st["Q_per_ch"])
     np.testing.assert_array_equal(qs[0], qs[1])
     np.testing.assert_array_equal(qs[0], qs[2])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# k_band4s (band4s.hip): the fused band kernel with its work divided between front and back waves.  Same arithmetic, operation for
+# operation, as the one-wave-per-channel k_band4f<4, 0> it replaces on the border-free strips: bits, not tolerances.
+@pytest.mark.parametrize("W,H,F,fps,disp", [
+    (1200, 144, 3, 60, "standard_4k"),        # five strips: three of them away from the border (front / back waves), two levels fused
+    (736, 416, 5, 30, "standard_fhd"),        # four strips (the last one 16 columns), several row segments, odd frame count
+    (1446, 333, 2, 60, "standard_hdr_pq"),    # W % 4 == 2 (partial-lane border kernel beside the split kernel), odd height
+    (3840, 270, 2, 60, "standard_4k"),        # the bench clip's width: 14 of 16 strips on the split kernel
+])
+def test_split_band_kernel_matches_the_one_wave_layout(W, H, F, fps, disp):
+    import colorvideovdp_amd as cv
+    from colorvideovdp_amd import _capi
+    t, r = _fuse_clip(W, H, F, W - H)
+    runs = {}
+    for layout in (0, 1):
+        m = cv.cvvdp(display_name=disp)
+        m.fuse_mode, m.band_layout = 1, layout
+        jod, stats = m.predict(t, r, dim_order="BCFHW", frames_per_second=fps)
+        pyr = []
+        hh, ww = H, W
+        for l in range(min(3, stats["Q_per_ch"].shape[-1])):
+            pyr.append(m.debug_buffer(_capi.BUF_GPYR, l)[:8 * F * hh * ww].view(8, F, hh, ww).cpu().numpy().copy())
+            hh, ww = (hh + 1) // 2, (ww + 1) // 2
+        runs[layout] = (float(jod), stats["Q_per_ch"], pyr, m.fused_levels)
+    assert runs[0][3] == runs[1][3] >= 1
+    for l, (a, b) in enumerate(zip(runs[0][2], runs[1][2])):
+        np.testing.assert_array_equal(a, b, err_msg=f"pyramid level {l}")
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    assert runs[0][0] == runs[1][0]

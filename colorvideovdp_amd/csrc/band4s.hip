@@ -21,6 +21,7 @@
 // image's left / right border run here (EDGE = 0 of band4f.hip); the border strips keep k_band4f<4, 1 / 2> on the edge stream.
 // Reference arithmetic: lpyr_dec.py:186-239,386-408, cvvdp_metric.py:835-856,945-950,963-971 (see band4.hip / band4f.hip).
 #include <type_traits>
+#include <utility>
 #include "kernels.h"
 
 namespace cvvdp {
@@ -45,7 +46,21 @@ __device__ __forceinline__ void s_lds_write4(float* p, const float (&v)[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+template <class F, int... Us>
+__device__ __forceinline__ void s_for_seq(F&& f, std::integer_sequence<int, Us...>) { (f(std::integral_constant<int, Us>{}), ...); }
+
 }  // namespace
+
+#ifndef CVVDP_BAND4S_RING
+#define CVVDP_BAND4S_RING 8         // rows of the front waves' register ring (STREAM LOADS)
+#endif
+
+// timing-only diagnostics (tools/build_variant.sh; results wrong by construction): S_DIAG_NOBAR drops the block barriers of the row loops
+#ifdef S_DIAG_NOBAR
+#define S_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define S_SYNC() __syncthreads()
+#endif
 
 __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
   constexpr int NCH = 4, NP = 8;
@@ -92,6 +107,9 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
 #ifndef S_DIAG_BACK_ONLY
   if (front) {
     // =============================================================================================== FRONT: stream, reduce, expand rows
+#ifdef S_PRIO_FRONT
+    __builtin_amdgcn_s_setprio(S_PRIO_FRONT);
+#endif
     const int64_t P = (int64_t)H * W, Pc = (int64_t)Hc * Wc;
     const int64_t gps = (int64_t)a.items_cap * P, gcps = (int64_t)a.items_cap * Pc;
     const float* gT = a.g + (int64_t)item * P + (2 * c) * gps;
@@ -166,8 +184,15 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
         const int own_end = seg == a.n_seg - 1 ? Hc : (ye >> 1);
         if (interior && m1 >= (ys >> 1) && m1 < own_end) {
           const int64_t o = (int64_t)m1 * Wc + (cb + 2 * j);
+#if defined(S_DIAG_NO_STORE)
+          if (emitted.x == 1.2345e-30f) { *reinterpret_cast<v2f*>(g1T + o) = v2f{emitted.x, emitted.y}; }
+#elif defined(S_DIAG_PLAIN_STORE)
+          *reinterpret_cast<v2f*>(g1T + o) = v2f{emitted.x, emitted.y};
+          *reinterpret_cast<v2f*>(g1R + o) = v2f{emitted.z, emitted.w};
+#else
           __builtin_nontemporal_store(v2f{emitted.x, emitted.y}, reinterpret_cast<v2f*>(g1T + o));
           __builtin_nontemporal_store(v2f{emitted.z, emitted.w}, reinterpret_cast<v2f*>(g1R + o));
+#endif
         }
       }
     };
@@ -197,40 +222,62 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
     };
 
     // ---- STREAM LOADS (band4f.hip): issued from inline assembly, waited for with one exact count per step.
-    // The ring holds SIX rows (k_band4f: eight): row s+1 leaves for the back in phase 1 of step s, before row s+7 is requested into
-    // the same slot in phase 2 (the barrier between them has drained the LDS write), and the neighbour samples need one set, not two
-    // (row s+6's are requested after row s+5's were used).
-    //   phase 2 of step s:  neighbour samples of row s+6 (4 loads), rows s+7 of the two planes (2 loads) -> ring slot (s+7) % 6 = (s+1) % 6
-    //   start of step s:    needs ring slot (s+5) % 6 and the neighbour samples of row s+5; younger: the 2 row loads of step s-1 -> vmcnt(2)
-    v4f ringT[6], ringR[6];
-    v2f nbLT, nbLR;
-    float nbRT, nbRR;
+    // The front wave alone at two rows in flight ran at 5.4 ms for level 0 of 4K x 64 (profiles/r04_dev_notes.txt 1): each wave
+    // waited for memory it had asked for one phase earlier.  The ring therefore holds S_RING rows (the front has the registers: 77 at
+    // six rows): row s+1 leaves for the back in phase 1 of step s, and its slot takes row s+S_RING+1 in phase 2, so rows s+6 ..
+    // s+S_RING are in flight during step s; the neighbour samples (columns fc0-2, fc0-1, fc0+4) have two sets by row parity and
+    // are requested two steps before their row is consumed.
+    //   phase 2 of step s:  neighbour samples of row s+7 (4 loads) -> set (s+7) & 1,  rows s+S_RING+1 of the two planes (2 loads)
+    //   start of step s:    needs ring slot (s+5) % S_RING and neighbour set (s+5) & 1; younger than those: the 2 row loads of step
+    //                       s-2, the 6 loads of step s-1 -> vmcnt(8)   (stores count too: that only makes the wait stricter)
+    constexpr int S_RING = CVVDP_BAND4S_RING;
+    static_assert(S_RING >= 8 && S_RING % 2 == 0, "vmcnt(8) of the row step assumes rows s+6.. are older than the neighbour set of row s+5");
+    v4f ringT[S_RING], ringR[S_RING];
+    v2f nbLT[2], nbLR[2];
+    float nbRT[2], nbRR[2];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { ringT[i] = 0.0f; ringR[i] = 0.0f; }
-    nbLT = 0.0f; nbLR = 0.0f; nbRT = 0.0f; nbRR = 0.0f;
+    for (int i = 0; i < S_RING; ++i) { ringT[i] = 0.0f; ringR[i] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { nbLT[i] = 0.0f; nbLR[i] = 0.0f; nbRT[i] = 0.0f; nbRR[i] = 0.0f; }
 #ifdef CVVDP_SAFE_LOADS
     // `make safe`: the same kernel with ordinary loads the compiler tracks and waits for itself (the dynamic check of the hand-managed ones)
 #define S_ROWPTR(plane, row, off) (reinterpret_cast<const char*>((plane) + (int64_t)(row) * W) + (off))
 #define S_LOAD4(dst, off, plane, row) dst = *reinterpret_cast<const v4f*>(S_ROWPTR(plane, row, off))
 #define S_LOADL(dst, off, plane, row) dst = *reinterpret_cast<const v2f*>(S_ROWPTR(plane, row, off) - 8)
 #define S_LOADR(dst, off, plane, row) dst = *reinterpret_cast<const float*>(S_ROWPTR(plane, row, off) + 16)
-#define S_WAIT2(...) do { } while (0)
-#define S_DRAIN() do { } while (0)
+#define S_WAIT8(...) do { } while (0)
 #else
 #define S_LOAD4(dst, off, plane, row) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W))
 #define S_LOADL(dst, off, plane, row) asm volatile("global_load_dwordx2 %0, %1, %2 offset:-8" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W))
 #define S_LOADR(dst, off, plane, row) asm volatile("global_load_dword %0, %1, %2 offset:16" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W))
-#define S_WAIT2(a0, a1, a2, a3, a4, a5) asm volatile("s_waitcnt vmcnt(2)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5))
+#ifdef S_DIAG_NO_NB
+#define S_WAITN "s_waitcnt vmcnt(4)"
+#else
+#define S_WAITN "s_waitcnt vmcnt(8)"
+#endif
+#define S_WAIT8(a0, a1, a2, a3, a4, a5) asm volatile(S_WAITN : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5))
+#endif
     // (the drain names every register a load may still be heading for: without that use the compiler sees the last rows' loads as dead
     // values and hands their registers to temporaries while the loads are in flight)
-#define S_DRAIN() asm volatile("s_waitcnt vmcnt(0)" : "+v"(ringT[0]), "+v"(ringT[1]), "+v"(ringT[2]), "+v"(ringT[3]), "+v"(ringT[4]), "+v"(ringT[5]), \
-                               "+v"(ringR[0]), "+v"(ringR[1]), "+v"(ringR[2]), "+v"(ringR[3]), "+v"(ringR[4]), "+v"(ringR[5]), \
-                               "+v"(nbLT), "+v"(nbLR), "+v"(nbRT), "+v"(nbRR))
+    auto drain = [&]() {
+#ifndef CVVDP_SAFE_LOADS
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(nbLT[0]), "+v"(nbLT[1]), "+v"(nbLR[0]), "+v"(nbLR[1]), "+v"(nbRT[0]), "+v"(nbRT[1]), "+v"(nbRR[0]), "+v"(nbRR[1]));
+#pragma unroll
+      for (int i = 0; i < S_RING; ++i) asm volatile("" : "+v"(ringT[i]), "+v"(ringR[i]));
 #endif
+    };
     auto rowc = [&](int r) { return min(max(r, 0), H - 1); };       // rows outside the image: any valid row (their weight is 0)
+    auto load_nb = [&](auto p_, int row) {
+      constexpr int PS = decltype(p_)::value;
+      (void)&nbLT; (void)&nbLR; (void)&nbRT; (void)&nbRR; (void)&goff; (void)&gT; (void)&gR; (void)&W;   // (asm operands alone do not capture)
+      S_LOADL(nbLT[PS], goff, gT, row);
+      S_LOADR(nbRT[PS], goff, gT, row);
+      S_LOADL(nbLR[PS], goff, gR, row);
+      S_LOADR(nbRR[PS], goff, gR, row);
+    };
 
     // ---- prologue: rows r_start-4 .. r_start+4 prime the reduce (three complete coarse rows in the window, two partial ones),
-    // rows r_start .. r_start+4 stay in ring slots 0 .. 4, the rows after them are requested
+    // rows r_start+1 .. r_start+4 stay in ring slots 1 .. 4, the rows after them are requested in the order the steps' count assumes
     {
       auto ld4 = [&](const float* plane, int r) -> v4f {
         return *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(plane + (int64_t)rowc(r) * W) + goff);
@@ -257,83 +304,77 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
         }
       }
       if (r_start == 0) cA = cB;                                      // coarse row -1 does not exist: the expand clamps to row 0
-      S_LOAD4(ringT[5], goff, gT, rowc(r_start + 5));
-      S_LOAD4(ringR[5], goff, gR, rowc(r_start + 5));
-      S_LOADL(nbLT, goff, gT, rowc(r_start + 5));
-      S_LOADR(nbRT, goff, gT, rowc(r_start + 5));
-      S_LOADL(nbLR, goff, gR, rowc(r_start + 5));
-      S_LOADR(nbRR, goff, gR, rowc(r_start + 5));
-      S_LOAD4(ringT[0], goff, gT, rowc(r_start + 6));
-      S_LOAD4(ringR[0], goff, gR, rowc(r_start + 6));
+#pragma unroll
+      for (int k = 5; k <= S_RING - 2; ++k) {
+        S_LOAD4(ringT[k], goff, gT, rowc(r_start + k));
+        S_LOAD4(ringR[k], goff, gR, rowc(r_start + k));
+      }
+      load_nb(std::integral_constant<int, 1>{}, rowc(r_start + 5));
+      S_LOAD4(ringT[S_RING - 1], goff, gT, rowc(r_start + S_RING - 1));
+      S_LOAD4(ringR[S_RING - 1], goff, gR, rowc(r_start + S_RING - 1));
+      load_nb(std::integral_constant<int, 0>{}, rowc(r_start + 6));
+      S_LOAD4(ringT[0], goff, gT, rowc(r_start + S_RING));
+      S_LOAD4(ringR[0], goff, gR, rowc(r_start + S_RING));
       coarse_finish(0, std::false_type{}, false, cC);                 // vertical expand of row r_start (even)
     }
     __syncthreads();
     lum_prep(0);
     __syncthreads();
 
-    // one real row r (0 <= r < H); U = (r - r_start) mod 6 = its ring slot
+    // one real row r (0 <= r < H); U = (r - r_start) mod S_RING = its ring slot
     auto step = [&](int r, auto u_) {
       constexpr int U = decltype(u_)::value;
       constexpr bool ODD = (U & 1) != 0;
-      constexpr int S5 = (U + 5) % 6, S1 = (U + 1) % 6;
+      constexpr int S5 = (U + 5) % S_RING, S1 = (U + 1) % S_RING, P5 = (U + 5) & 1;
       (void)&ringT; (void)&ringR; (void)&nbLT; (void)&nbLR; (void)&nbRT; (void)&nbRR; (void)&goff; (void)&gT; (void)&gR; (void)&W;
-      S_WAIT2(ringT[S5], ringR[S5], nbLT, nbLR, nbRT, nbRR);
+      S_WAIT8(ringT[S5], ringR[S5], nbLT[P5], nbLR[P5], nbRT[P5], nbRR[P5]);
       // ================= phase 1: level-l row r+5 into the reduce; an even row completes a coarse row, which rolls the window for row r+1
       float4 emitted = cC;
-      consume(r + 5, std::integral_constant<bool, !ODD>{}, ringT[S5], ringR[S5], nbLT, nbRT, nbLR, nbRR, emitted);
+      consume(r + 5, std::integral_constant<bool, !ODD>{}, ringT[S5], ringR[S5], nbLT[P5], nbRT[P5], nbLR[P5], nbRR[P5], emitted);
       coarse_finish(ODD ? 0 : 1, std::integral_constant<bool, !ODD>{}, ODD, emitted);   // vertical expand of row r+1
-      *reinterpret_cast<v4f*>(&s_g[ODD ? 0 : 1][2 * c][4 * j]) = ringT[S1];             // raw row r+1 for the back (arrived four steps ago)
+#ifndef S_DIAG_NO_SG
+      *reinterpret_cast<v4f*>(&s_g[ODD ? 0 : 1][2 * c][4 * j]) = ringT[S1];             // raw row r+1 for the back (arrived long ago)
       *reinterpret_cast<v4f*>(&s_g[ODD ? 0 : 1][2 * c + 1][4 * j]) = ringR[S1];
-      __syncthreads();
+#endif
+      S_SYNC();
       // ================= phase 2
       {
-        const int r6 = rowc(r + 6), r7 = rowc(r + 7);
-        S_LOADL(nbLT, goff, gT, r6);
-        S_LOADR(nbRT, goff, gT, r6);
-        S_LOADL(nbLR, goff, gR, r6);
-        S_LOADR(nbRR, goff, gR, r6);
-        S_LOAD4(ringT[S1], goff, gT, r7);                             // (r + 7) % 6 == (r + 1) % 6: the slot that has just been handed on
-        S_LOAD4(ringR[S1], goff, gR, r7);
+#ifndef S_DIAG_NO_NB
+        load_nb(std::integral_constant<int, P5>{}, rowc(r + 7));      // set (r+7) & 1 == (r+5) & 1: consumed in phase 1
+#endif
+        const int rn = rowc(r + S_RING + 1);
+        S_LOAD4(ringT[S1], goff, gT, rn);                             // (r + S_RING + 1) % S_RING == (r + 1) % S_RING: the slot that has just been handed on
+        S_LOAD4(ringR[S1], goff, gR, rn);
       }
+#ifndef S_DIAG_NO_LUM
       lum_prep(ODD ? 0 : 1);
-      __syncthreads();
+#endif
+      S_SYNC();
     };
 
-    // Whole groups of six rows without an exit inside (a `break` in the unrolled body makes the structuriser route every exit through
-    // the loop's latch, and the layout-order ISA check -- tools/check_band4_isa.py -- then sees paths "exit -> latch -> header" that no
-    // execution takes); the last 0..5 rows of the march follow as straight-line code.
+    // Whole groups of S_RING rows without an exit inside (a `break` in the unrolled body makes the structuriser route every exit
+    // through the loop's latch, and the layout-order ISA check -- tools/check_band4_isa.py -- then sees paths "exit -> latch ->
+    // header" that no execution takes); the last 0 .. S_RING-1 rows of the march follow as straight-line code (nested ifs).
     int r = r_start;
-    for (; r + 6 <= rreal; r += 6) {
-      step(r, std::integral_constant<int, 0>{});
-      step(r + 1, std::integral_constant<int, 1>{});
-      step(r + 2, std::integral_constant<int, 2>{});
-      step(r + 3, std::integral_constant<int, 3>{});
-      step(r + 4, std::integral_constant<int, 4>{});
-      step(r + 5, std::integral_constant<int, 5>{});
-    }
-    if (r < rreal) {
-      step(r, std::integral_constant<int, 0>{});
-      if (r + 1 < rreal) {
-        step(r + 1, std::integral_constant<int, 1>{});
-        if (r + 2 < rreal) {
-          step(r + 2, std::integral_constant<int, 2>{});
-          if (r + 3 < rreal) {
-            step(r + 3, std::integral_constant<int, 3>{});
-            if (r + 4 < rreal) step(r + 4, std::integral_constant<int, 4>{});
-          }
-        }
+    for (; r + S_RING <= rreal; r += S_RING)
+      s_for_seq([&](auto u_) { step(r + decltype(u_)::value, u_); }, std::make_integer_sequence<int, S_RING>{});
+    auto tail = [&](auto self, int rr, auto u_) -> void {
+      constexpr int U = decltype(u_)::value;
+      if (rr < rreal) {
+        step(rr, u_);
+        if constexpr (U + 1 < S_RING - 1) self(self, rr + 1, std::integral_constant<int, U + 1>{});
       }
-    }
-    S_DRAIN();
+    };
+    tail(tail, r, std::integral_constant<int, 0>{});
+    drain();
     for (r = rreal; r < rend; ++r) {          // reflected rows below the image: the back works from its window, the front only keeps step
-      __syncthreads();
-      __syncthreads();
+      S_SYNC();
+      S_SYNC();
     }
 #undef S_LOAD4
 #undef S_LOADL
 #undef S_LOADR
-#undef S_WAIT2
-#undef S_DRAIN
+#undef S_WAIT8
 #ifdef CVVDP_SAFE_LOADS
 #undef S_ROWPTR
 #endif
@@ -342,6 +383,9 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
 #ifndef S_DIAG_FRONT_ONLY
   if (!front) {
     // =============================================================================================== BACK: contrast, blurs, masking, pooling
+#ifdef S_PRIO_BACK
+    __builtin_amdgcn_s_setprio(S_PRIO_BACK);
+#endif
     const float e0 = a.kx[0], e1 = a.kx[1], eo = a.kx[2];
     const float mask_p = a.mask_p, eps_p = a.eps_p;
     const float qc = a.q[c];
@@ -472,18 +516,18 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
           winA[2 * ms] = h[0]; winA[2 * ms + 1] = h[1]; winB[2 * ms] = h[2]; winB[2 * ms + 1] = h[3];
         }
       }
-      __syncthreads();
+      S_SYNC();
       // ================= phase 2
       vblur(r - S_R);
       slot = slot == S_BW - 1 ? 0 : slot + 1;
       k7 = k7 == S_R ? 0 : k7 + 1;
-      __syncthreads();
+      S_SYNC();
     };
     // one reflected row below the image (r >= H): its horizontally blurred row is that of row 2(H-1) - r, still in the window
     auto tail_step = [&](int r) {
       const int yprev = r - 1 - S_R;
       if (interior && yprev >= ys) stage3c(k7);
-      __syncthreads();
+      S_SYNC();
       if (interior) {
         const int back = 2 * (r - (H - 1));                           // 2, 4, .. 12 rows back
         const int src = slot >= back ? slot - back : slot - back + S_BW;
@@ -493,7 +537,7 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
       vblur(r - S_R);
       slot = slot == S_BW - 1 ? 0 : slot + 1;
       k7 = k7 == S_R ? 0 : k7 + 1;
-      __syncthreads();
+      S_SYNC();
     };
 
     int r = r_start;                                       // (even)

@@ -13,6 +13,6 @@ for lib in "" "$@"; do
     i=$((i+1)); rm -rf /tmp/sqb$i
     ( cd $R && CVVDP_DEV_KNOBS=1 CVVDP_LIB=$lib timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/sqb$i -o sq -- python bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-profile > /tmp/sqb$i.log 2>&1 )
     db=$(find /tmp/sqb$i -name "*.db" | head -1)
-    python $R/tools/rocpd_summary.py $db | grep -E "k_band4<4, false, false, false, false>" | awk '$0 ~ / 6144 /' | awk '{printf "%-26s %18.0f\n", $(NF-3), $NF}'
+    python $R/tools/rocpd_summary.py $db | grep -E "${SQ_KERNEL:-k_band4s}" | awk -v wg="${SQ_WG:-5376}" '$0 ~ (" " wg " ")' | awk '{printf "%-26s %18.0f\n", $(NF-3), $NF}'
   done
 done

@@ -320,6 +320,9 @@ def main():
     ap.add_argument("--heatmap-format", default="u8", choices=["u8", "f16"],
                     help="what the heat-map sink takes: the writers' 8-bit RGB frames made on the GPU (3 B/pixel over PCIe, the default: "
                          "what a heat-map video / PNG sequence needs) or the reference's fp16 planes (6 B/pixel)")
+    ap.add_argument("--heatmap-sink", default="host", choices=["host", "device"],
+                    help="where the heat-map frames go: page-locked host memory over PCIe (the reference's semantics: 8K x 256 8-bit RGB frames "
+                         "are 25.5 GB = 0.49 s of the link, more than the kernels) or a consumer on the GPU (nothing crosses PCIe in the step)")
     ap.add_argument("--distogram", action="store_true", help="also write the distogram of the last step (default for 8k256pq)")
     ap.add_argument("--gen", default=None, choices=["cpu", "gpu"], help="frame generator (default: cpu when a reference fixture exists for the clip)")
     ap.add_argument("--frames", type=int, default=None, help="override the workload's frame count (per GPU or total)")
@@ -390,7 +393,7 @@ def main():
         clip = ResidentClip(n_total, lo, first + count, H, W, fps, dtype, device, gen=gen, pq_range=args.workload == "8k256pq")
     if dist_on:
         m.set_frame_sharding("world")
-    sink = HeatmapFrameMeans(uint8=args.heatmap_format == "u8") if heat is not None else None      # the heat map leaves the GPU block by block (bounded host memory)
+    sink = HeatmapFrameMeans(uint8=args.heatmap_format == "u8", device=args.heatmap_sink == "device") if heat is not None else None      # the heat map leaves the GPU block by block (bounded host memory)
 
     def step():
         return m.predict_video_source(clip, heatmap_sink=sink) if sink is not None else m.predict_video_source(clip)
@@ -542,7 +545,12 @@ def main():
     if sink is not None:
         out["heatmap_frames_streamed_per_step"] = sink.frames_seen // (args.steps + args.warmup)
         out["config"]["heatmap_sink"] = ("HeatmapFrameMeans: every frame crosses PCIe into page-locked memory, the host then reads 1/256 of "
-                                         "its pixels (a writer's encode / file cost is NOT in the figure)")
+                                         "its pixels (a writer's encode / file cost is NOT in the figure)") if args.heatmap_sink == "host" else \
+                                        "HeatmapFrameMeans(device=True): the frames are consumed on the GPU (per-frame means), nothing crosses PCIe in the step"
+        if args.heatmap_sink == "host":
+            hm_bytes = (1 if heat == "raw" else 3) * (1 if sink.wants_uint8 else 2) * W * H * count
+            out["pcie"] = {"heatmap_bytes_per_step": hm_bytes, "GBs_if_the_step_were_only_this_copy": round(hm_bytes / (dt / args.steps) / 1e9, 1),
+                           "note": "the heat map's D2H stream bounds this step when the figure approaches what the link sustains (~52 GB/s measured on these boxes)"}
         out["config"]["heatmap_sink_format"] = "uint8 RGB frames (as written to .mp4 / .png), 3 B/pixel D2H" if sink.wants_uint8 else "fp16 planes, 6 B/pixel D2H"
     if distogram:
         try:

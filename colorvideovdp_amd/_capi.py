@@ -12,7 +12,7 @@ MAX_WINDOW = 256
 CSF_NODES = 32
 PROF_N = 6
 PROF_NAMES = ("photometry", "temporal_fir", "pyr_reduce", "band_level0", "band_rest", "heatmap")
-ABI_VERSION = 11
+ABI_VERSION = 12
 RESIZE_MODES = {"nearest": 0, "bilinear": 1, "bicubic": 2, "area": 3}   # CVVDP_RESIZE_*
 
 U8, U16, F16, F32, F32_DKL, YUV8, YUV16 = range(7)
@@ -57,6 +57,7 @@ class Clip(C.Structure):
         ("debug_dump", C.c_int32),
         ("raw_halo", C.c_int32), ("total_frames", C.c_int32),
         ("feature_size", C.c_int32), ("fuse_mode", C.c_int32), ("band_layout", C.c_int32),
+        ("defer_bands", C.c_int32), ("score_frames", C.c_int32),
         ("taps", C.c_float * (4 * MAX_FILTER_LEN)),
         ("csf_rows", C.c_float * (MAX_LEVELS * 4 * CSF_NODES)),
     ]
@@ -93,6 +94,7 @@ SYMBOLS = {
     "cvvdp_process_image": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cvvdp_get_q_per_ch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvvdp_pool_jod": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "cvvdp_score_frames": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "cvvdp_get_heatmap": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "cvvdp_get_heatmap_rgb8": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "cvvdp_debug_buffer": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),

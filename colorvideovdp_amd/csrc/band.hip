@@ -58,7 +58,7 @@ __global__ __launch_bounds__(BT) void k_band(BandArgs a) {
   const int64_t P = (int64_t)H * W, Pc = (int64_t)Hc * Wc;
   const float* g = a.g + (int64_t)item * P;
   const float* gc = a.gc + (int64_t)item * Pc;
-  const int64_t gps = (int64_t)a.items_cap * P, gcps = (int64_t)a.items_cap * Pc;
+  const int64_t gps = (int64_t)a.items_cap * P, gcps = (int64_t)a.items_cap_c * Pc;
 
   // coarse column range this strip can touch (after reflection every xx lies in [xlo, xhi))
   const int xlo = max(x0 - R, 0), xhi = min(x0 - R + BT, W);

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64 * NCH, FEAT ? 2 : 3) void k_band4(BandArgs a) {
   const int ys = seg * a.seg_h, ye = min(H, ys + a.seg_h);   // ys is even (core.cpp keeps seg_h even)
 
   const int64_t P = (int64_t)H * W, Pc = (int64_t)Hc * Wc;
-  const int64_t gps = (int64_t)a.items_cap * P, gcps = (int64_t)a.items_cap * Pc;
+  const int64_t gps = (int64_t)a.items_cap * P, gcps = (int64_t)a.items_cap_c * Pc;
   const float* gT = a.g + (int64_t)item * P + (2 * c) * gps;      // test plane of this channel (scalar base)
   const float* gR = gT + gps;                                      // reference plane
   // stage-1 role of this lane: plane 2c + (j>>5), coarse chunk j&31
@@ -387,12 +387,21 @@ __global__ __launch_bounds__(64 * NCH, FEAT ? 2 : 3) void k_band4(BandArgs a) {
 #ifndef B4_NT_STR
 #define B4_NT_STR ""
 #endif
+#ifdef CVVDP_SAFE_LOADS
+// `make safe`: the same kernel with ordinary loads the compiler tracks and waits for itself (tests/test_safe_loads.py)
+#define B4_G_LOAD(dst, plane, row) \
+  do { const f4u q_ = *reinterpret_cast<const f4u*>(reinterpret_cast<const char*>((plane) + (int64_t)(row) * W) + goff); dst = v4f{q_.x, q_.y, q_.z, q_.w}; } while (0)
+#define B4_C_LOAD(dst, row) do { const f4u q_ = *reinterpret_cast<const f4u*>(gcl + (int64_t)(row) * Wc); dst = v4f{q_.x, q_.y, q_.z, q_.w}; } while (0)
+#define B4_WAIT_EVEN() do { } while (0)
+#define B4_WAIT_ODD() do { } while (0)
+#else
 #define B4_G_LOAD(dst, plane, row) \
   asm volatile("global_load_dwordx4 %0, %1, %2" B4_NT_STR : "+v"(dst) : "v"(goff), "s"((plane) + (int64_t)(row) * W))
 #define B4_C_LOAD(dst, row) \
   asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(gcl + (int64_t)(row) * Wc))
 #define B4_WAIT_EVEN() asm volatile("s_waitcnt vmcnt(3)" : "+v"(p0T), "+v"(p0R))
 #define B4_WAIT_ODD() asm volatile("s_waitcnt vmcnt(2)" : "+v"(p1T), "+v"(p1R), "+v"(cN))
+#endif
 // (the builtin, not asm: the compiler's own wait-count bookkeeping must see that nothing of ITS loads is pending either, or it
 // keeps re-waiting inside the next loop; 0x0F70 = vmcnt(0) with the other counters at their maxima on gfx9)
 #define B4_DRAIN() do { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" : "+v"(p0T), "+v"(p0R), "+v"(p1T), "+v"(p1R), "+v"(cN)); } while (0)

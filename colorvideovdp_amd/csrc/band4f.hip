@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   const bool top_seg = seg == 0;
 
   const int64_t P = (int64_t)H * W, Pc = (int64_t)Hc * Wc;
-  const int64_t gps = (int64_t)a.items_cap * P, gcps = (int64_t)a.items_cap * Pc;
+  const int64_t gps = (int64_t)a.items_cap * P, gcps = (int64_t)a.items_cap_c * Pc;
   const float* gT = a.g + (int64_t)item * P + (2 * c) * gps;
   const float* gR = gT + gps;
   float* g1T = a.g1_out + (int64_t)item * Pc + (2 * c) * gcps;     // level l+1 planes of this channel, written here
@@ -336,10 +336,24 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   for (int i = 0; i < 8; ++i) { ringT[i] = 0.0f; ringR[i] = 0.0f; }
 #pragma unroll
   for (int i = 0; i < 2; ++i) { nbLT[i] = 0.0f; nbLR[i] = 0.0f; nbRT[i] = 0.0f; nbRR[i] = 0.0f; }
+#ifdef CVVDP_SAFE_LOADS
+  // `make safe`: the same kernel with ordinary loads the compiler tracks and waits for itself (the dynamic check of the hand-managed ones,
+  // tests/test_safe_loads.py)
+#define F_ROWPTR(plane, row, off) (reinterpret_cast<const char*>((plane) + (int64_t)(row) * W) + (off))
+  struct __attribute__((packed, aligned(4))) u4 { float x, y, z, w; };     // (rows of W % 4 == 2 frames are 8-byte aligned)
+  struct __attribute__((packed, aligned(4))) u2 { float x, y; };
+#define F_LOAD4(dst, off, plane, row) do { const u4 q_ = *reinterpret_cast<const u4*>(F_ROWPTR(plane, row, off)); dst = v4f{q_.x, q_.y, q_.z, q_.w}; } while (0)
+#define F_LOAD2(dst, off, plane, row) do { const u2 q_ = *reinterpret_cast<const u2*>(F_ROWPTR(plane, row, off)); dst = v2f{q_.x, q_.y}; } while (0)
+#define F_LOAD1(dst, off, plane, row) dst = *reinterpret_cast<const float*>(F_ROWPTR(plane, row, off))
+#define F_WAIT2(...) do { } while (0)
+#define F_DRAIN() do { } while (0)
+#else
 #define F_LOAD4(dst, off, plane, row) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W))
 #define F_LOAD2(dst, off, plane, row) asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W))
 #define F_LOAD1(dst, off, plane, row) asm volatile("global_load_dword %0, %1, %2" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W))
+#define F_WAIT2(a0, a1, a2, a3, a4, a5) asm volatile("s_waitcnt vmcnt(2)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5))
 #define F_DRAIN() do { __builtin_amdgcn_s_waitcnt(0x0F70); } while (0)
+#endif
   auto rowc = [&](int r) { return min(max(r, 0), H - 1); };       // rows outside the image: any valid row (their weight is 0)
 
   // image-edge mirror roles of the contrast stage (band4.hip): reflect padding of the blur at the left / right image border
@@ -396,8 +410,7 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
     constexpr int U = decltype(u_)::value;
     constexpr bool ODD = (U & 1) != 0;
     (void)&ringT; (void)&ringR; (void)&nbLT; (void)&nbLR; (void)&nbRT; (void)&nbRR; (void)&goff; (void)&loff; (void)&roff; (void)&gT; (void)&gR; (void)&W;
-    asm volatile("s_waitcnt vmcnt(2)" : "+v"(ringT[(U + 5) & 7]), "+v"(ringR[(U + 5) & 7]), "+v"(nbLT[(U + 5) & 1]), "+v"(nbLR[(U + 5) & 1]),
-                 "+v"(nbRT[(U + 5) & 1]), "+v"(nbRR[(U + 5) & 1]));
+    F_WAIT2(ringT[(U + 5) & 7], ringR[(U + 5) & 7], nbLT[(U + 5) & 1], nbLR[(U + 5) & 1], nbRT[(U + 5) & 1], nbRR[(U + 5) & 1]);
     // (EDGE == 2: the partial lane's rows are shifted into place where they are USED, twice per row -- a ring register that is
     // rewritten stops being pinned, and the compiler then copies ring registers around while their loads are in flight)
     auto placed = [&](v4f q) -> v4f { return part ? v4f{q.z, q.w, 0.0f, 0.0f} : q; };
@@ -580,6 +593,10 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
 #undef F_LOAD2
 #undef F_LOAD1
 #undef F_DRAIN
+#undef F_WAIT2
+#ifdef CVVDP_SAFE_LOADS
+#undef F_ROWPTR
+#endif
 
 bool band4f_supported(int H, int W) { return (W & 1) == 0 && W >= 32 && H >= 32; }
 

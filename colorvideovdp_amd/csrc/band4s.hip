@@ -111,7 +111,7 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
     __builtin_amdgcn_s_setprio(S_PRIO_FRONT);
 #endif
     const int64_t P = (int64_t)H * W, Pc = (int64_t)Hc * Wc;
-    const int64_t gps = (int64_t)a.items_cap * P, gcps = (int64_t)a.items_cap * Pc;
+    const int64_t gps = (int64_t)a.items_cap * P, gcps = (int64_t)a.items_cap_c * Pc;
     const float* gT = a.g + (int64_t)item * P + (2 * c) * gps;
     const float* gR = gT + gps;
     float* g1T = a.g1_out + (int64_t)item * Pc + (2 * c) * gcps;     // level l+1 planes of this channel, written here
@@ -242,8 +242,10 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
 #ifdef CVVDP_SAFE_LOADS
     // `make safe`: the same kernel with ordinary loads the compiler tracks and waits for itself (the dynamic check of the hand-managed ones)
 #define S_ROWPTR(plane, row, off) (reinterpret_cast<const char*>((plane) + (int64_t)(row) * W) + (off))
-#define S_LOAD4(dst, off, plane, row) dst = *reinterpret_cast<const v4f*>(S_ROWPTR(plane, row, off))
-#define S_LOADL(dst, off, plane, row) dst = *reinterpret_cast<const v2f*>(S_ROWPTR(plane, row, off) - 8)
+    struct __attribute__((packed, aligned(4))) u4 { float x, y, z, w; };     // (rows of W % 4 == 2 frames are 8-byte aligned)
+    struct __attribute__((packed, aligned(4))) u2 { float x, y; };
+#define S_LOAD4(dst, off, plane, row) do { const u4 q_ = *reinterpret_cast<const u4*>(S_ROWPTR(plane, row, off)); dst = v4f{q_.x, q_.y, q_.z, q_.w}; } while (0)
+#define S_LOADL(dst, off, plane, row) do { const u2 q_ = *reinterpret_cast<const u2*>(S_ROWPTR(plane, row, off) - 8); dst = v2f{q_.x, q_.y}; } while (0)
 #define S_LOADR(dst, off, plane, row) dst = *reinterpret_cast<const float*>(S_ROWPTR(plane, row, off) + 16)
 #define S_WAIT8(...) do { } while (0)
 #else

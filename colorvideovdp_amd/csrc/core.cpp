@@ -36,12 +36,16 @@ struct cvvdp_handle {
   cvvdp_params p{};
   cvvdp_clip c{};
   bool configured = false;
-  int nch = 4, L = 0, items_cap = 0;
+  int nch = 4, L = 0;
+  // items allocated per plane: of level 0 (the temporal stage's block) and of everything behind it (levels 1.., partial sums, heat
+  // bands).  The two differ for clips scored in pieces (cvvdp_clip.defer_bands): a long temporal block, short band / heat-map pieces.
+  int items_cap = 0, items_cap_s = 0;
+  int filtered_frames = 0, filtered_q0 = 0;   // defer_bands: what the last cvvdp_process_block* left in level 0
   std::vector<Level> lv;
   size_t hist_off = 0, hist_shadow_off = 0, partial_off = 0, q_off = 0, hstats_off = 0, hcurve_off = 0;
   size_t ws_floats = 0;
   float* ws = nullptr;
-  int last_items = 0;
+  int last_items = 0, last_item0 = 0;     // the items the band stage ran on last (count; offset inside level 0)
   float eotf_tab[256];          // per-code display model of 8-bit sources (eotf_table), made once in cvvdp_create
   bool eotf_tab_ok = false;
   bool prof = false;
@@ -89,6 +93,7 @@ int check_launch(cvvdp_handle* h, const char* what) {
 }
 
 float* gbase(const cvvdp_handle* h, int level, int set) { return h->ws + h->lv[level].g_off + (size_t)set * h->pyr_set_floats; }
+int level_cap(const cvvdp_handle* h, int level) { return level == 0 ? h->items_cap : h->items_cap_s; }
 
 int ensure_pipeline_objects(cvvdp_handle* h) {
   if (!h->pipeline || h->band_stream) return CVVDP_OK;
@@ -141,9 +146,10 @@ void heat_weights(const cvvdp_handle* h, bool baseband, float* w) {
 }
 
 // levels [l_begin, L-1) + baseband + heat-map reconstruction; fused: only levels [l_begin, l_end) on k_band4f (each writes the next level)
-int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStream_t s, int l_begin = 0, int l_end = -1, bool fused = false);
+// item0: the first item of level 0 the call works on (clips scored in pieces; everything behind level 0 starts at item 0)
+int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStream_t s, int l_begin = 0, int l_end = -1, bool fused = false, int item0 = 0);
 
-int run_pyramid_and_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, hipStream_t s) {
+int run_pyramid_and_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, hipStream_t s, int item0 = 0) {
   const int B = h->c.batch, items = n_frames * B, L = h->L, nch = h->nch;
   const float K[5] = {0.25f - 0.4f / 2.0f, 0.25f, 0.4f, 0.25f, 0.25f - 0.4f / 2.0f};  // lpyr_dec.py:179
   const int set = h->pipeline ? h->cur_set : 0;
@@ -153,30 +159,30 @@ int run_pyramid_and_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, hip
   // is left, then the remaining bands.
   const int F = h->pipeline ? 0 : h->fuse_levels;
   if (F > 0) {
-    if (int e = run_bands(h, n_frames, q_frame_offset, 0, s, 0, F, true)) return e;
+    if (int e = run_bands(h, n_frames, q_frame_offset, 0, s, 0, F, true, item0)) return e;
   }
   for (int l = F; l + 1 < L; ++l) {
     ProfScope ps(h, CVVDP_PROF_REDUCE, s);
     if (fuse2 && l + 2 < L && reduce2_supported(h->lv[l].H, h->lv[l].W)) {   // two levels per pass
       Reduce2Args r{};
-      r.in = gbase(h, l, set); r.out1 = gbase(h, l + 1, set); r.out2 = gbase(h, l + 2, set);
+      r.in = gbase(h, l, set) + (l == 0 ? (size_t)item0 * h->lv[0].P : 0); r.out1 = gbase(h, l + 1, set); r.out2 = gbase(h, l + 2, set);
       r.H = h->lv[l].H; r.W = h->lv[l].W; r.H1 = h->lv[l + 1].H; r.W1 = h->lv[l + 1].W; r.H2 = h->lv[l + 2].H; r.W2 = h->lv[l + 2].W;
-      r.n_img = items; r.img_cap = h->items_cap; r.n_planes = 2 * nch;
+      r.n_img = items; r.img_cap = level_cap(h, l); r.img_cap_out = h->items_cap_s; r.n_planes = 2 * nch;
       for (int i = 0; i < 5; ++i) r.k[i] = K[i];
       launch_reduce2(r, s);
       ++l;
       continue;
     }
     ReduceArgs r{};
-    r.in = gbase(h, l, set);
+    r.in = gbase(h, l, set) + (l == 0 ? (size_t)item0 * h->lv[0].P : 0);
     r.out = gbase(h, l + 1, set);
     r.H = h->lv[l].H; r.W = h->lv[l].W; r.Ho = h->lv[l + 1].H; r.Wo = h->lv[l + 1].W;
-    r.n_img = items; r.img_cap = h->items_cap; r.n_planes = 2 * nch;
+    r.n_img = items; r.img_cap = level_cap(h, l); r.img_cap_out = h->items_cap_s; r.n_planes = 2 * nch;
     for (int i = 0; i < 5; ++i) r.k[i] = K[i];
     launch_reduce(r, s);
   }
   if (int e = check_launch(h, "reduce")) return e;
-  if (!h->pipeline) return run_bands(h, n_frames, q_frame_offset, 0, s, F);
+  if (!h->pipeline) return run_bands(h, n_frames, q_frame_offset, 0, s, F, -1, false, item0);
   // hand the pyramid set to the band stage on the internal stream; the caller's stream is free to start
   // the next block's FIR + reduce into the other set
   if (int e = ensure_pipeline_objects(h)) return e;
@@ -189,7 +195,7 @@ int run_pyramid_and_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, hip
   return CVVDP_OK;
 }
 
-int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStream_t s, int l_begin, int l_end, bool fused) {
+int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStream_t s, int l_begin, int l_end, bool fused, int item0) {
   const int B = h->c.batch, items = n_frames * B, L = h->L, nch = h->nch;
   if (l_end < 0) l_end = L - 1;
   const float K[5] = {0.25f - 0.4f / 2.0f, 0.25f, 0.4f, 0.25f, 0.25f - 0.4f / 2.0f};  // lpyr_dec.py:179
@@ -220,10 +226,10 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
     hipStream_t s = (fork && l >= 2) ? h->aux_stream[l & 1] : s_main;
     ProfScope ps(h, l == 0 ? CVVDP_PROF_BAND0 : CVVDP_PROF_BAND_REST, s);
     BandArgs a{};
-    a.g = gbase(h, l, set);
+    a.g = gbase(h, l, set) + (l == 0 ? (size_t)item0 * h->lv[0].P : 0);
     a.gc = gbase(h, l + 1, set);
     a.H = lv.H; a.W = lv.W; a.Hc = h->lv[l + 1].H; a.Wc = h->lv[l + 1].W;
-    a.items = items; a.items_cap = h->items_cap; a.nch = nch;
+    a.items = items; a.items_cap = level_cap(h, l); a.items_cap_c = h->items_cap_s; a.nch = nch;
     a.seg_h = lv.seg_h; a.n_seg = lv.n_seg; a.n_strip = lv.n_strip;
     a.band_mul = (l == 0) ? 1.0f : 2.0f;  // lpyr_dec.py:60-66 (baseband handled separately)
     fill_csf(h, l, a.lut);
@@ -301,7 +307,7 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
     hipStream_t s = fork ? h->aux_stream[(L - 1) & 1] : s_main;
     ProfScope ps(h, CVVDP_PROF_BAND_REST, s);
     BaseArgs b{};
-    b.g = gbase(h, L - 1, set); b.H = lv.H; b.W = lv.W; b.items = items; b.items_cap = h->items_cap; b.nch = nch;
+    b.g = gbase(h, L - 1, set) + (L == 1 ? (size_t)item0 * h->lv[0].P : 0); b.H = lv.H; b.W = lv.W; b.items = items; b.items_cap = level_cap(h, L - 1); b.nch = nch;
     fill_csf(h, L - 1, b.lut);
     b.logL_first = h->p.csf_logL_first; b.logL_last = h->p.csf_logL_last; b.sens_mul = h->p.sens_mul;
     b.q_out = h->ws + h->q_off; b.q_frames = h->c.n_frames; b.q_levels = L; b.q_frame_offset = q_frame_offset;
@@ -332,6 +338,7 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
     if (int e = check_launch(h, "heat reconstruct")) return e;
   }
   h->last_items = items;
+  h->last_item0 = item0;
   return CVVDP_OK;
 }
 
@@ -406,10 +413,19 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     return fail(h, CVVDP_E_UNSUPPORTED, "feature_size > 0 cannot be combined with a heat map or debug_dump");
   if (c.fuse_mode < 0 || c.fuse_mode > 2) return fail(h, CVVDP_E_ARG, "fuse_mode must be 0, 1 or 2");
   if (c.band_layout < 0 || c.band_layout > 1) return fail(h, CVVDP_E_ARG, "band_layout must be 0 or 1");
+  if (c.defer_bands < 0 || c.defer_bands > 1) return fail(h, CVVDP_E_ARG, "defer_bands must be 0 or 1");
+  if (c.defer_bands) {
+    if (!c.is_video) return fail(h, CVVDP_E_ARG, "defer_bands is for video clips");
+    if (c.score_frames < 1 || c.score_frames > c.block_frames) return fail(h, CVVDP_E_ARG, "score_frames must be in 1 .. block_frames");
+    // (the per-pixel dump and feature planes of level 0 are laid out with the level's own item count)
+    if (c.debug_dump || c.feature_size > 0) return fail(h, CVVDP_E_UNSUPPORTED, "defer_bands cannot be combined with debug_dump or features");
+  }
   h->c = c;
   h->nch = c.is_video ? 4 : 3;
   h->L = c.n_levels;
   h->items_cap = (c.is_video ? c.block_frames : 1) * c.batch;
+  h->items_cap_s = c.defer_bands ? c.score_frames * c.batch : h->items_cap;
+  h->filtered_frames = 0;
   h->lv.assign(h->L, Level());
   int H = c.height, W = c.width;
   const int pad = h->p.blur_radius;
@@ -487,20 +503,20 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     // off by default: since the kernels were tuned, overlapping the band stage of block k with FIR + reduce of block
     // k+1 no longer gains anything (4K x 256: 84-87 ms either way) and costs a second pyramid set of workspace
     static const bool pipe_env = dev_knob("CVVDP_PIPELINE", 0) != 0;
-    h->pipeline = pipe_env && c.is_video && c.heatmap == CVVDP_HEATMAP_NONE && !c.debug_dump && c.feature_size <= 0 && c.n_frames > c.block_frames;
+    h->pipeline = pipe_env && c.is_video && c.heatmap == CVVDP_HEATMAP_NONE && !c.debug_dump && c.feature_size <= 0 && c.n_frames > c.block_frames && !c.defer_bands;
     const size_t start = off;
-    for (auto& lv : h->lv) { lv.g_off = off; off += align_up((size_t)2 * h->nch * h->items_cap * lv.P); }
+    for (int l = 0; l < h->L; ++l) { Level& lv = h->lv[l]; lv.g_off = off; off += align_up((size_t)2 * h->nch * level_cap(h, l) * lv.P); }
     h->pyr_set_floats = off - start;
     if (h->pipeline) off += h->pyr_set_floats;   // second pyramid set
     h->cur_set = 0;
   }
   h->partial_off = off;
-  for (auto& lv : h->lv) { lv.partial_off = off; off += align_up((size_t)h->items_cap * lv.n_strip * lv.n_seg * 4); }
+  for (auto& lv : h->lv) { lv.partial_off = off; off += align_up((size_t)h->items_cap_s * lv.n_strip * lv.n_seg * 4); }
   h->q_off = off; off += align_up((size_t)c.batch * h->nch * c.n_frames * h->L);
   if (c.heatmap != CVVDP_HEATMAP_NONE) {
-    for (auto& lv : h->lv) { lv.heat_off = off; off += align_up((size_t)h->items_cap * lv.P); }
-    h->hstats_off = off; off += align_up((size_t)h->items_cap * kHeatStatsWords);
-    h->hcurve_off = off; off += align_up((size_t)h->items_cap * kHeatCurveWords);
+    for (auto& lv : h->lv) { lv.heat_off = off; off += align_up((size_t)h->items_cap_s * lv.P); }
+    h->hstats_off = off; off += align_up((size_t)h->items_cap_s * kHeatStatsWords);
+    h->hcurve_off = off; off += align_up((size_t)h->items_cap_s * kHeatCurveWords);
   }
   for (auto& lv : h->lv) {
     if (c.debug_dump || (c.feature_size > 0 && !lv.feat4)) { lv.dd_off = off; off += align_up((size_t)4 * h->items_cap * lv.P); }
@@ -513,7 +529,7 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
   h->ws_floats = off;
   h->ws = nullptr;
   h->configured = true;
-  h->last_items = 0;
+  h->last_items = 0; h->last_item0 = 0;
   return CVVDP_OK;
 }
 
@@ -741,6 +757,7 @@ static int process_block_impl(cvvdp_handle* h, const void* t, const void* r, int
     launch_fir(f, h->ws + h->hist_shadow_off, s);
   }
   if (int e = check_launch(h, "temporal fir")) return e;
+  if (c.defer_bands) { h->filtered_frames = n_frames; h->filtered_q0 = q_frame_offset; return CVVDP_OK; }   // scored in pieces: cvvdp_score_frames
   return run_pyramid_and_bands(h, n_frames, q_frame_offset, s);
 }
 
@@ -765,7 +782,18 @@ int cvvdp_process_block_filtered(cvvdp_handle* h, const void* t, const void* r, 
     launch_put_planes(a, s);
   }
   if (int e = check_launch(h, "put planes")) return e;
+  if (c.defer_bands) { h->filtered_frames = n_frames; h->filtered_q0 = q_frame_offset; return CVVDP_OK; }
   return run_pyramid_and_bands(h, n_frames, q_frame_offset, s);
+}
+
+int cvvdp_score_frames(cvvdp_handle* h, int32_t first, int32_t n_frames, void* stream) {
+  if (!h || !h->ws) return fail(h, CVVDP_E_STATE, "no workspace bound");
+  const cvvdp_clip& c = h->c;
+  if (!c.is_video || !c.defer_bands) return fail(h, CVVDP_E_STATE, "the clip was not configured with defer_bands");
+  if (first < 0 || n_frames < 1 || n_frames > c.score_frames || first + n_frames > h->filtered_frames)
+    return fail(h, CVVDP_E_ARG, "frames %d .. %d are not a piece (at most %d frames) of the %d frames the last block left", first, first + n_frames - 1,
+                c.score_frames, h->filtered_frames);
+  return run_pyramid_and_bands(h, n_frames, h->filtered_q0 + first, static_cast<hipStream_t>(stream), first * c.batch);
 }
 
 int cvvdp_get_features(cvvdp_handle* h, int32_t band, int32_t n_frames, float* dev_out, void* stream) {
@@ -786,7 +814,7 @@ int cvvdp_get_features(cvvdp_handle* h, int32_t band, int32_t n_frames, float* d
   }
   FeatPoolArgs a{};
   a.tr = h->ws + lv.fd_off; a.d = h->ws + lv.dd_off;
-  a.H = lv.H; a.W = lv.W; a.items = h->last_items; a.items_cap = h->items_cap; a.nch = h->nch; a.fs = h->c.feature_size;
+  a.H = lv.H; a.W = lv.W; a.items = h->last_items; a.items_cap = h->items_cap_s; a.nch = h->nch; a.fs = h->c.feature_size;
   a.Hc = (lv.H + a.fs - 1) / a.fs; a.Wc = (lv.W + a.fs - 1) / a.fs;
   // the band kernels' T', R' carry the channel gain (cvvdp_metric.py:835); the features are |T_f|*S without it (cvvdp_ml_metric.py:355)
   for (int c = 0; c < 4; ++c) a.inv_gain[c] = band == h->L - 1 ? 1.0f : 1.0f / h->p.ch_gain[c];
@@ -838,7 +866,7 @@ static int get_heatmap_impl(cvvdp_handle* h, int32_t n_frames, void* dev_out_f16
   hipStream_t s = static_cast<hipStream_t>(stream);
   HeatArgs a{};
   a.recon = h->ws + h->lv[0].heat_off;
-  a.ctx = h->ws + h->lv[0].g_off;  // plane 0 = test Y-sustained (cvvdp_metric.py:400)
+  a.ctx = h->ws + h->lv[0].g_off + (size_t)h->last_item0 * h->lv[0].P;  // plane 0 = test Y-sustained (cvvdp_metric.py:400)
   a.P = (int)h->lv[0].P; a.items = h->last_items; a.mode = h->c.heatmap;
   a.jod_a = h->p.jod_a; a.jod_exp = h->p.jod_exp;
   a.jod_lin = h->p.jod_a * powf(0.1f, h->p.jod_exp - 1.0f);
@@ -877,14 +905,14 @@ int cvvdp_debug_buffer(cvvdp_handle* h, int32_t which, int32_t level, void** dev
     case CVVDP_BUF_HIST:
       if (!h->c.is_video) return fail(h, CVVDP_E_STATE, "no temporal history for images");
       *dev_ptr = h->ws + h->hist_off; *n_floats = (size_t)2 * 3 * (fir_kernel_len(h->c.filter_len) - 1) * h->c.batch * h->lv[0].P; break;
-    case CVVDP_BUF_GPYR: *dev_ptr = h->ws + lv.g_off; *n_floats = (size_t)2 * h->nch * h->items_cap * lv.P; break;
+    case CVVDP_BUF_GPYR: *dev_ptr = h->ws + lv.g_off; *n_floats = (size_t)2 * h->nch * level_cap(h, level) * lv.P; break;
     case CVVDP_BUF_DDUMP:
       if (!h->c.debug_dump && h->c.feature_size <= 0) return fail(h, CVVDP_E_STATE, "debug_dump not enabled");
       if (lv.feat4 && !h->c.debug_dump) return fail(h, CVVDP_E_STATE, "level %d keeps column sums in features mode, not per-pixel D planes", level);
-      *dev_ptr = h->ws + lv.dd_off; *n_floats = (size_t)4 * h->items_cap * lv.P; break;
+      *dev_ptr = h->ws + lv.dd_off; *n_floats = (size_t)4 * h->items_cap_s * lv.P; break;
     case CVVDP_BUF_HEAT:
       if (h->c.heatmap == CVVDP_HEATMAP_NONE) return fail(h, CVVDP_E_STATE, "heat map not enabled");
-      *dev_ptr = h->ws + lv.heat_off; *n_floats = (size_t)h->items_cap * lv.P; break;
+      *dev_ptr = h->ws + lv.heat_off; *n_floats = (size_t)h->items_cap_s * lv.P; break;
     case CVVDP_BUF_Q: *dev_ptr = h->ws + h->q_off; *n_floats = (size_t)h->c.batch * h->nch * h->c.n_frames * h->L; break;
     default: return fail(h, CVVDP_E_ARG, "unknown buffer");
   }

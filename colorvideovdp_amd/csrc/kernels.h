@@ -123,7 +123,8 @@ struct ReduceArgs {
   const float* in;   // [planes*items][H*W]
   float* out;        // [planes*items][Ho*Wo]
   int32_t H, W, Ho, Wo, n_img;   // n_img = images actually processed per plane
-  int32_t img_cap;               // images allocated per plane (plane stride = img_cap * size)
+  int32_t img_cap;               // images allocated per plane of the input level (plane stride = img_cap * size)
+  int32_t img_cap_out;           // ... and of the output level (the two differ for level 0 of clips scored in pieces, core.cpp)
   int32_t n_planes;
   float k[5];
 };
@@ -131,7 +132,7 @@ void launch_reduce(const ReduceArgs& a, hipStream_t s);
 struct Reduce2Args {         // two levels per pass: l -> l+1 -> l+2
   const float* in;           // level l
   float *out1, *out2;        // levels l+1, l+2
-  int32_t H, W, H1, W1, H2, W2, n_img, img_cap, n_planes;
+  int32_t H, W, H1, W1, H2, W2, n_img, img_cap, img_cap_out, n_planes;   // img_cap: input level, img_cap_out: both output levels
   int32_t seg2;              // level-(l+2) rows per thread (set by launch_reduce2)
   float k[5];
 };
@@ -141,9 +142,9 @@ void launch_reduce2(const Reduce2Args& a, hipStream_t s);
 // ---------------------------------------------------------------- fused band kernel (K3..K7)
 struct BandArgs {
   const float* g;    // level l   planes [2*nch][items_cap][H*W]
-  const float* gc;   // level l+1 planes [2*nch][items_cap][Hc*Wc]
+  const float* gc;   // level l+1 planes [2*nch][items_cap_c][Hc*Wc]
   int32_t H, W, Hc, Wc;
-  int32_t items, items_cap, nch;
+  int32_t items, items_cap, items_cap_c, nch;   // items_cap_c: items allocated per plane of level l+1 (gc, g1_out)
   int32_t seg_h, n_seg, n_strip;
   int32_t per_xcd;   // k_band4: work units per XCD (set by launch_band4)
   int32_t strip0, n_strip_l;   // k_band4: this launch covers strips strip0 .. strip0 + n_strip_l - 1 (set by launch_band4)

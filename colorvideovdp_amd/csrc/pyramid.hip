@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
   const int img = blockIdx.z;                       // plane * n_img + item
   const int plane = img / a.n_img, it = img - plane * a.n_img;
   const float* in = a.in + ((int64_t)plane * a.img_cap + it) * a.H * a.W;
-  float* out = a.out + ((int64_t)plane * a.img_cap + it) * a.Ho * a.Wo;
+  float* out = a.out + ((int64_t)plane * a.img_cap_out + it) * a.Ho * a.Wo;
   const int oy0 = blockIdx.y * RT, ox0 = blockIdx.x * RT;
   const int iy0 = 2 * oy0 - 2, ix0 = 2 * ox0 - 2;
   const int t = threadIdx.x;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_reduce_vec(ReduceArgs a) {
   const int img = blockIdx.z;
   const int plane = img / a.n_img, it = img - plane * a.n_img;
   const float* in = a.in + ((int64_t)plane * a.img_cap + it) * a.H * a.W;
-  float* out = a.out + ((int64_t)plane * a.img_cap + it) * a.Ho * a.Wo;
+  float* out = a.out + ((int64_t)plane * a.img_cap_out + it) * a.Ho * a.Wo;
   const int ox = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (ox >= a.Wo) return;
   const bool first = ox == 0, last = ox + 4 >= a.Wo;
@@ -267,8 +267,9 @@ __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
   const int plane = img / a.n_img, it = img - plane * a.n_img;
   const int64_t ib = (int64_t)plane * a.img_cap + it;
   const float* in = a.in + ib * a.H * a.W;
-  float* out1 = a.out1 + ib * a.H1 * a.W1;
-  float* out2 = a.out2 + ib * a.H2 * a.W2;
+  const int64_t ob = (int64_t)plane * a.img_cap_out + it;
+  float* out1 = a.out1 + ob * a.H1 * a.W1;
+  float* out2 = a.out2 + ob * a.H2 * a.W2;
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   const int v = wave * R2_LANES + lane - 1;                 // quad index: level-(l+1) columns 4v .. 4v+3
   const int nq = ANYW ? (a.W1 + 3) >> 2 : a.W1 >> 2;

@@ -98,6 +98,7 @@ class cvvdp(vq_metric):
         self._ws = None
         self._shard = None
         self.debug_dump = False
+        self.score_frames = None      # heat-map clips resident in HBM: frames per band / heat-map piece of a long temporal block (None: 16; >= the block: one piece)
         self.band_layout = 0          # cvvdp_clip.band_layout: 0 = front / back waves on fused levels (normal use); 1 = one wave per channel (A/B switch, same bits)
         self.fuse_mode = 0            # cvvdp_clip.fuse_mode: 0 = the core decides (normal use); 1 / 2 = fused band kernels everywhere / nowhere (tests)
         self.set_display_model(display_name, display_photometry=display_photometry, display_geometry=display_geometry,
@@ -334,10 +335,24 @@ class cvvdp(vq_metric):
                 # that cannot be had falls back to 64-frame blocks and below (_score_range).
                 nb_abs = int((_total * 0.30 - fixed) // per_frame)
                 nb = max(64, min(nb, nb_abs))
-            nb = min(nb, 16 if self.do_heatmap else (_capi.MAX_WINDOW - fl + 1 if long_ok else 64))
+            # Heat-map clips resident in HBM: the temporal stage runs over a long block and the band / heat-map stage walks it in
+            # 16-frame pieces (cvvdp_clip.defer_bands), so the copy of a piece still overlaps the kernels of the next one while the
+            # fl-1 halo frames are unpacked once per long block, not once per 16 frames (8K PQ x 256: temporal stage 94 -> ~60 ms).
+            # Level 0 of the long block is what costs memory (8 planes: 1 GB per 8K frame): sized from an absolute share of the device.
+            pieces_ok = device_raw and self.do_heatmap and getattr(self, "_feature_out", None) is None
+            if pieces_ok:
+                piece = self._piece_frames()
+                fixed_p = fixed + piece * (pix * batch * (2 * nch * 4 * 0.34) + pix * 16)
+                nb_abs = int((_total * 0.30 - fixed_p) // (pix * batch * 2 * nch * 4))
+                nb = max(piece, min(int((budget - fixed_p) // (pix * batch * 2 * nch * 4)), nb_abs, 64))
+            else:
+                nb = min(nb, 16 if self.do_heatmap else (_capi.MAX_WINDOW - fl + 1 if long_ok else 64))
             if host_resident and n_frames > 24:
                 nb = min(nb, 16)   # the upload of block k+1 (side stream, worker thread) hides behind the kernels of block k
         return max(1, min(nb, n_frames, _capi.MAX_WINDOW - fl + 1))
+
+    def _piece_frames(self):
+        return 16 if self.score_frames is None else max(1, int(self.score_frames))
 
     def _alloc_workspace(self, nbytes):
         """The one device allocation of a call (torch's caching allocator; the core allocates nothing itself)."""
@@ -446,7 +461,7 @@ class cvvdp(vq_metric):
         # The clip description (temporal taps, CSF rows per band, block size) depends only on the geometry: repeated
         # calls on clips of the same shape reuse it, so the first kernel is not held back by ~0.4 ms of host set-up.
         key = (height, width, N_total, first, count, B, C, is_image, None if is_image else float(vs.get_frames_per_second()), self.heatmap,
-               bool(self.debug_dump), int(self.fuse_mode), int(self.band_layout), self.block_frames, self.gpu_mem, float(self.pix_per_deg), self._cfg_version, prefiltered, getattr(self, "_feature_out", None) is not None,
+               bool(self.debug_dump), int(self.fuse_mode), int(self.band_layout), self.score_frames, self.block_frames, self.gpu_mem, float(self.pix_per_deg), self._cfg_version, prefiltered, getattr(self, "_feature_out", None) is not None,
                self._host_resident(vs))
         cached = getattr(self, "_clip_cache", None)
         if cached is not None and cached[0] == key:
@@ -481,6 +496,10 @@ class cvvdp(vq_metric):
                 nb = self._pick_block_frames(height * width, B, count, fl, nch, self._host_resident(vs), bool(clip.raw_halo))
                 clip.filter_len, clip.block_frames = fl, nb
                 self.last_block_frames = nb
+                # heat-map clips resident in HBM are scored in pieces of a long temporal block (see _pick_block_frames)
+                piece = self._piece_frames()
+                if self.do_heatmap and clip.raw_halo and not prefiltered and not self.debug_dump and nb > piece:
+                    clip.defer_bands, clip.score_frames = 1, piece
             rows = np.zeros((_capi.MAX_LEVELS, 4, _capi.CSF_NODES), dtype=f32)
             for bb in range(L):
                 rows[bb] = self.csf_table.rows(rho_band[bb])
@@ -504,7 +523,10 @@ class cvvdp(vq_metric):
                 torch.cuda.empty_cache()
                 clip.block_frames = 64 if nb_now > 64 else max(1, nb_now // 2)
                 self.last_block_frames = int(clip.block_frames)
+                if clip.defer_bands and clip.block_frames <= clip.score_frames:
+                    clip.defer_bands, clip.score_frames = 0, 0
         _capi.check(self._handle, lib.cvvdp_bind_workspace(self._handle, self._ws.data_ptr(), self._ws.numel()), "cvvdp_bind_workspace")
+        self.last_score_frames = int(clip.score_frames) if clip.defer_bands else 0      # (0: every block scored whole)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         heatmap = None
         hm_ch = 1 if self.heatmap == "raw" else 3
@@ -515,13 +537,20 @@ class cvvdp(vq_metric):
             # the kernels of block k+1 run.  Host memory is bounded by 2 blocks whatever the clip length.
             # A sink that writes 8-bit frames anyway (PNG, ffmpeg) sets `wants_uint8`: the conversion the reference's writers do on
             # the host is then done by the heat-map kernel, and 3 instead of 6 bytes per pixel cross PCIe
-            nb_max = 1 if is_image else clip.block_frames
+            nb_max = 1 if is_image else (clip.score_frames if clip.defer_bands else clip.block_frames)
             sink_u8 = bool(getattr(heatmap_sink, "wants_uint8", False))
+            # A sink that consumes the frames ON THE GPU (statistics, a device-side encoder, a later bulk copy) sets `wants_device`:
+            # it is called with the device tensor of each piece, on the current stream, and nothing crosses PCIe here.  (8K x 256
+            # frames of 8-bit RGB are 25.5 GB: 0.49 s of a PCIe 5 x16 link at the 52 GB/s it sustains -- more than all the kernels.)
+            sink_dev = bool(getattr(heatmap_sink, "wants_device", False))
             stage = getattr(self, "_hm_stage", None)
-            if stage is None or stage[0].numel() < hm_ch * nb_max * height * width:       # (fp16 elements: enough for either format)
+            if sink_dev:
+                stage = "device"
+            elif stage is None or stage == "device" or stage[0].numel() < hm_ch * nb_max * height * width:       # (fp16 elements: enough for either format)
                 stage = self._hm_stage = [torch.empty(hm_ch * nb_max * height * width, dtype=torch.float16, device="cpu", pin_memory=True) for _ in range(2)]
-            copy_stream = getattr(self, "_hm_stream", None) or torch.cuda.Stream(self.device)
-            self._hm_stream = copy_stream
+            if not sink_dev:
+                copy_stream = getattr(self, "_hm_stream", None) or torch.cuda.Stream(self.device)
+                self._hm_stream = copy_stream
         elif self.do_heatmap:
             # The reference keeps the whole fp16 heat map on the CPU (cvvdp_metric.py:344).  Page-locked memory
             # + copies on a side stream keep the D2H traffic (6 B/pixel) off the compute stream.
@@ -556,6 +585,9 @@ class cvvdp(vq_metric):
             else:
                 buf = torch.empty((hm_ch, n, height, width), dtype=torch.float16, device=self.device)
                 _capi.check(self._handle, lib.cvvdp_get_heatmap(self._handle, n, buf.data_ptr(), stream), "cvvdp_get_heatmap")
+            if stage == "device":
+                heatmap_sink(first + ff, buf if sink_u8 else buf.view(1, hm_ch, n, height, width))
+                return
             if stage is not None:
                 flush_sink(keep=1)                         # the buffer about to be overwritten has been consumed
                 dst = stage[1] if (pending_sink and pending_sink[0][3] == 0) else stage[0]
@@ -696,7 +728,13 @@ class cvvdp(vq_metric):
                         st, sr = self._strides(t, r)
                         rc = lib.cvvdp_process_block(self._handle, t.data_ptr(), r.data_ptr(), third, st, sr, ff - lo, hist_c, n, ff - first, stream)
                         _capi.check(self._handle, rc, "cvvdp_process_block")
-                    if self.do_heatmap:
+                    if clip.defer_bands:
+                        # the block is filtered; bands, pooling and heat maps piece by piece (the copy of a piece overlaps the next one's kernels)
+                        for p0 in range(0, n, clip.score_frames):
+                            m = min(clip.score_frames, n - p0)
+                            _capi.check(self._handle, lib.cvvdp_score_frames(self._handle, p0, m, stream), "cvvdp_score_frames")
+                            fetch_heatmap(ff - first + p0, m)
+                    elif self.do_heatmap:
                         fetch_heatmap(ff - first, n)
                     if feat_out is not None:
                         fetch_features(ff - first, n)

@@ -8,7 +8,9 @@ into the reference's format) or one .npy file with the reference's array layout;
 PATH, HeatmapVideoWriter pipes the frames into it and produces the reference's .mp4 directly.
 
 A sink is any callable `sink(first_frame, frames)`; `frames` is a float16 CPU tensor [1, 1|3, n, H, W] with values in
-[0, 1] (colour-mapped modes) that is only valid during the call.
+[0, 1] (colour-mapped modes) that is only valid during the call.  Attributes a sink may set: `wants_uint8` (frames arrive as
+uint8 [n, H, W, C], converted on the GPU the way the reference's writers convert them) and `wants_device` (frames arrive as
+DEVICE tensors on the current stream and never cross PCIe here: statistics, a device-side consumer, one bulk copy later).
 """
 import os
 import shutil
@@ -122,13 +124,23 @@ class HeatmapFrameMeans:
     """Keeps only a per-frame mean of every colour plane, taken over every `step`-th pixel in both directions (a cheap sink
     for benchmarks and tests: the host only touches 1/step^2 of the 6 bytes per pixel that crossed PCIe)."""
 
-    def __init__(self, step=16, uint8=False):
+    def __init__(self, step=16, uint8=False, device=False):
         self.step = step
+        self.wants_device = device        # take the frames as device tensors (nothing crosses PCIe; the means are reduced on the GPU and fetched in close())
         self.wants_uint8 = uint8          # take the frames as a file writer would (uint8 [n, H, W, C]); means are then of the 8-bit codes / 255
         self.means = {}
         self.frames_seen = 0
 
     def __call__(self, first_frame, frames):
+        if frames.device.type != "cpu":
+            if frames.dtype == torch.uint8:
+                m = frames[:, ::self.step, ::self.step].float().mean(dim=(1, 2)).T / 255.0               # [C, n], stays on the device
+            else:
+                m = frames[0, :, :, ::self.step, ::self.step].float().mean(dim=(2, 3))
+            self._pending = getattr(self, "_pending", [])
+            self._pending.append((first_frame, m))
+            self.frames_seen += m.shape[1]
+            return
         if frames.dtype == torch.uint8:
             m = (frames[:, ::self.step, ::self.step].float().mean(dim=(1, 2)) / 255.0).numpy().T      # [C, n]
         else:
@@ -138,4 +150,9 @@ class HeatmapFrameMeans:
         self.frames_seen += m.shape[1]
 
     def close(self):
-        pass
+        for first_frame, m in getattr(self, "_pending", []):
+            m = m.cpu().numpy()
+            for i in range(m.shape[1]):
+                self.means[first_frame + i] = m[:, i].copy()
+        self._pending = []
+

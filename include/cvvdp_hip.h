@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CVVDP_ABI_VERSION 11
+#define CVVDP_ABI_VERSION 12
 #define CVVDP_MAX_FILTER_LEN 65 /* 0.25 s at up to 256 fps, cvvdp_metric.py:1059 */
 #define CVVDP_MAX_LEVELS 16
 #define CVVDP_MAX_WINDOW 256    /* filter_len - 1 + frames per block */
@@ -125,6 +125,14 @@ typedef struct cvvdp_clip {
   int32_t band_layout;          /* how a fused level's band kernel divides its work between waves.  0 (normal use): front / back waves
                                    (band4s.hip: 8 waves per block, four per SIMD); 1: one wave per channel (round 3's k_band4f everywhere,
                                    two per SIMD).  Same arithmetic, bit-identical results: 1 is the A/B switch of tests and benchmarks */
+  int32_t defer_bands;          /* 1: cvvdp_process_block* run the temporal stage only and leave the level-0 planes of the block (up to
+                                   block_frames frames) in the workspace; the caller scores them in pieces of at most score_frames frames
+                                   with cvvdp_score_frames.  For heat-map clips: the frames' heat maps leave the GPU piece by piece
+                                   (16 frames), while the temporal stage pays its filter_len-1 halo frames once per LONG block
+                                   (cvvdp_metric.py:554-560 has one window per clip; the block structure is this core's).  Everything
+                                   behind level 0 (coarser levels, partial sums, heat bands) is sized for score_frames.  Scores and heat
+                                   maps do not depend on either length.  Not with debug_dump or features */
+  int32_t score_frames;         /* frames per cvvdp_score_frames call at most (read when defer_bands is set) */
   float taps[4 * CVVDP_MAX_FILTER_LEN];                             /* F[c][k], not flipped */
   float csf_rows[CVVDP_MAX_LEVELS * 4 * CVVDP_CSF_NODES];           /* [band][ch][node] log10 S */
 } cvvdp_clip;
@@ -213,6 +221,12 @@ int cvvdp_unpack_yuv_resized(cvvdp_handle* h, const void* dev_codes, const cvvdp
 int cvvdp_process_block_filtered(cvvdp_handle* h, const void* dev_test, const void* dev_ref,
                                  const int64_t strides_test[5], const int64_t strides_ref[5], int32_t n_frames,
                                  int32_t q_frame_offset, void* stream);
+
+/* Clips configured with defer_bands: contrast pyramid, bands, pooling and heat-map bands of frames first .. first+n_frames-1 of the block
+ * the last cvvdp_process_block* call filtered (n_frames <= score_frames).  Q of those frames lands where cvvdp_process_block would have
+ * put it; cvvdp_get_heatmap* afterwards returns the heat maps of exactly these n_frames.  Pieces may be scored in any order, each
+ * frame once.  Reference: the per-frame body of predict_video_source, cvvdp_metric.py:596-744. */
+int cvvdp_score_frames(cvvdp_handle* h, int32_t first, int32_t n_frames, void* stream);
 
 /* Features for the ML heads: cvvdp_feature_pooling of |T_f|*S, |R_f|*S and D (cvvdp_ml_metric.py:77-107 called
  * at :355-358) for one band of the block processed last: mean and variance (E[x^2] - mean^2) over feature_size x

@@ -990,3 +990,88 @@ def test_split_band_kernel_matches_the_one_wave_layout(W, H, F, fps, disp):
         np.testing.assert_array_equal(a, b, err_msg=f"pyramid level {l}")
     np.testing.assert_array_equal(runs[0][1], runs[1][1])
     assert runs[0][0] == runs[1][0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Heat-map clips resident in HBM (cvvdp_clip.defer_bands, cvvdp_score_frames): a long temporal block, the band / heat-map stage in
+# pieces.  Neither length may change a bit of Q_per_ch or of the heat maps.
+@pytest.mark.parametrize("mode", ["supra-threshold", "raw"])
+def test_heatmap_clips_in_hbm_are_scored_in_pieces_of_a_long_temporal_block(mode):
+    import colorvideovdp_amd as cv
+    t, r = _fuse_clip(256, 144, 41, 5)
+    t, r = torch.as_tensor(t).cuda(), torch.as_tensor(r).cuda()
+    runs = []
+    #              block, piece -> (temporal block, piece; 0 = blocks scored whole)
+    for block, piece, want in ((16, None, (16, 0)), (None, None, (41, 16)), (41, 7, (41, 7)), (23, 5, (23, 5)), (41, 41, (41, 0)), (30, 16, (30, 16))):
+        m = cv.cvvdp(display_name="standard_fhd", heatmap=mode, block_frames=block)
+        m.score_frames = piece
+        jod, st = m.predict(t, r, dim_order="BCFHW", frames_per_second=30)
+        assert (m.last_block_frames, m.last_score_frames) == want
+        runs.append((float(jod), st["Q_per_ch"], st["heatmap"].clone()))
+    for jod, q, hm in runs[1:]:
+        assert jod == runs[0][0]
+        np.testing.assert_array_equal(q, runs[0][1])
+        assert torch.equal(hm, runs[0][2])
+    # the sink sees the pieces, in order
+    order = []
+    got = torch.zeros_like(runs[0][2])
+
+    def sink(first, frames):
+        order.append((first, frames.shape[2]))
+        got[:, :, first:first + frames.shape[2]] = frames
+
+    m = cv.cvvdp(display_name="standard_fhd", heatmap=mode, block_frames=23)
+    m.score_frames = 9
+    vs = cv.video_source_array(t, r, 30, dim_order="BCFHW", display_photometry=m.display_photometry)
+    _, st = m.predict_video_source(vs, heatmap_sink=sink)
+    assert order == [(0, 9), (9, 9), (18, 5), (23, 9), (32, 9)]
+    assert torch.equal(got, runs[0][2])
+    np.testing.assert_array_equal(st["Q_per_ch"], runs[0][1])
+
+
+def test_score_frames_argument_checks():
+    import ctypes
+    import colorvideovdp_amd as cv
+    from colorvideovdp_amd import _capi
+    t, r = _fuse_clip(64, 48, 12, 3)
+    t, r = torch.as_tensor(t).cuda(), torch.as_tensor(r).cuda()
+    m = cv.cvvdp(display_name="standard_fhd", heatmap="threshold", block_frames=12)
+    m.score_frames = 4
+    m.predict(t, r, dim_order="BCFHW", frames_per_second=30)
+    lib, s = _capi.lib(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.cvvdp_score_frames(m._handle, 0, 5, s) != 0              # more than score_frames
+    assert lib.cvvdp_score_frames(m._handle, 10, 4, s) != 0             # beyond the frames the last block left
+    assert lib.cvvdp_score_frames(m._handle, 8, 4, s) == 0
+    m2 = cv.cvvdp(display_name="standard_fhd")
+    m2.predict(t, r, dim_order="BCFHW", frames_per_second=30)
+    assert lib.cvvdp_score_frames(m2._handle, 0, 1, s) != 0             # not configured with defer_bands
+
+
+def test_device_heatmap_sink_gets_the_same_frames_without_pcie():
+    """A sink with wants_device is handed the device tensor of every piece (fp16 planes or the writers' uint8 frames)."""
+    import colorvideovdp_amd as cv
+    t, r = _fuse_clip(256, 144, 20, 6)
+    t, r = torch.as_tensor(t).cuda(), torch.as_tensor(r).cuda()
+    m = cv.cvvdp(display_name="standard_fhd", heatmap="threshold", block_frames=20)
+    m.score_frames = 8
+    _, full = m.predict(t, r, dim_order="BCFHW", frames_per_second=30)
+    vs = cv.video_source_array(t, r, 30, dim_order="BCFHW", display_photometry=m.display_photometry)
+    for u8 in (False, True):
+        seen = []
+
+        class Sink:
+            wants_device, wants_uint8 = True, u8
+
+            def __call__(self, first, frames):
+                assert frames.is_cuda
+                seen.append((first, frames.clone()))
+
+        _, st = m.predict_video_source(vs, heatmap_sink=Sink())
+        assert [f for f, _ in seen] == [0, 8, 16]
+        if u8:
+            got = torch.cat([x for _, x in seen], 0).cpu()                                     # [n, H, W, 3] uint8
+            from colorvideovdp_amd.heatmap_writers import heatmap_to_uint8
+            np.testing.assert_array_equal(got.numpy(), heatmap_to_uint8(full["heatmap"]))
+        else:
+            assert torch.equal(torch.cat([x for _, x in seen], 2).cpu(), full["heatmap"])
+        np.testing.assert_array_equal(st["Q_per_ch"], full["Q_per_ch"])

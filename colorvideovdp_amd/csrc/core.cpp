@@ -735,11 +735,11 @@ static int process_block_impl(cvvdp_handle* h, const void* t, const void* r, int
   for (int ch = 0; ch < 4; ++ch)
     for (int k = 0; k < std::min(2 * fl, CVVDP_MAX_FILTER_LEN); ++k)   // F.flip(0) (:556), written twice back to back so
       f.taps[ch * CVVDP_MAX_FILTER_LEN + k] = c.taps[ch * CVVDP_MAX_FILTER_LEN + (fl - 1 - (k % fl))];   // that a rotated view is contiguous
-  if (fl >= 3 && fl <= 17) {                   // rotating-window kernel: taps of positions 0..fl-2 twice, newest at [32]
+  if (fl >= 3 && 2 * (fl - 1) <= CVVDP_ROT_NEW) {   // rotating-window kernel (fl <= 31): taps of positions 0..fl-2 twice, newest at [CVVDP_ROT_NEW]
     const int M = fl - 1;
     for (int ch = 0; ch < 4; ++ch) {
       for (int i = 0; i < 2 * M; ++i) f.taps_rot[ch * CVVDP_ROT_TAPS + i] = c.taps[ch * CVVDP_MAX_FILTER_LEN + (fl - 1 - (i % M))];
-      f.taps_rot[ch * CVVDP_ROT_TAPS + 32] = c.taps[ch * CVVDP_MAX_FILTER_LEN + 0];   // position fl-1 (newest) <- F[0]
+      f.taps_rot[ch * CVVDP_ROT_TAPS + CVVDP_ROT_NEW] = c.taps[ch * CVVDP_MAX_FILTER_LEN + 0];   // position fl-1 (newest) <- F[0]
     }
   }
   for (int k = 0; k < fl_clip - 1; ++k) {

@@ -65,7 +65,8 @@ struct PutPlanesArgs {       // pre-filtered 4-channel frames -> the 8 level-0 p
 void launch_put_planes(const PutPlanesArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- temporal FIR (K1)
-constexpr int CVVDP_ROT_TAPS = 40;
+constexpr int CVVDP_ROT_TAPS = 64;     // k_fir_rot's tap table per channel: 2 (fl-1) rotated weights (fl <= 31), the newest frame's weight at CVVDP_ROT_NEW
+constexpr int CVVDP_ROT_NEW = 63;
 struct YuvArgs {            // planar Y'CbCr sources (video_source_yuv.py:79-124, 147-223); frame = Y plane, U plane, V plane
   int32_t Wc, Hc;           // chroma plane size
   float inv_fx, inv_fy;     // 1 / up-sampling factor (1 or 0.5) per axis
@@ -103,10 +104,11 @@ struct FirArgs {
   float* out;              // level-0 planes [plane][item][P]
   int64_t o_plane;         // items_cap * P
   float taps[4 * CVVDP_MAX_FILTER_LEN];     // flipped: taps[c][k] multiplies window position k
-  float taps_rot[4 * 40];                   // k_fir_rot: [c][i < 2(fl-1)] = weight of window position i mod (fl-1), [c][32] = newest
+  float taps_rot[4 * CVVDP_ROT_TAPS];       // k_fir_rot: [c][i < 2(fl-1)] = weight of window position i mod (fl-1), [c][CVVDP_ROT_NEW] = newest
   YuvArgs yuv;                              // used by the CVVDP_YUV* dtypes only
   int16_t hist_src[CVVDP_MAX_FILTER_LEN];   // window position k < fl-1: >= 0 raw frame index, < 0 history slot -1-e
 };
+static_assert(sizeof(FirArgs) <= 4096, "kernel arguments of the temporal kernels");
 void launch_fir(const FirArgs& a, float* hist_shadow, hipStream_t s);
 inline bool fir_has_register_window(int fl) { return fl == 7 || fl == 9 || fl == 13 || fl == 15 || fl == 17 || fl == 25 || fl == 31; }
 // Filter length the FIR kernels are run with: a filter that has no register-window instantiation of its own runs on the

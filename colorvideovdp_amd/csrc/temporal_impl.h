@@ -232,16 +232,17 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------
-// Fast path for FL <= 17 (24 .. 60 fps), one pixel per thread: the FL-deep window of each DKL plane is a register
-// vector; the newest frame is written to slot (frame index mod 17) with an M0-relative register write and
+// Fast path for FL <= 31 (24 .. 120 fps), one pixel per thread: the FL-deep window of each DKL plane is a register
+// vector; the newest frame is written to slot (frame index mod (FL-1)) with an M0-relative register write and
 // the taps are read rotated instead (scalar loads from a doubled tap table), so nothing is shifted and
-// the window costs 51 VGPRs: 5-6 waves per SIMD hide the HBM latency this kernel is bound by.
+// the window costs 51 VGPRs at FL <= 17 (5-6 waves per SIMD hide the HBM latency this kernel is bound by), 99 at 25 / 31 taps
+// (90 / 120 fps: k_fir_fused's shifted window made those rates VALU-bound at 0.33 of 8 TB/s).
 template <int DT, int FL>
 __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
   __shared__ float s_tab[DT == CVVDP_U8 ? 256 : 1];
   const bool use_lut = stage_eotf_table<DT>(a.dm, s_tab);
-  static_assert(FL >= 3 && FL <= 17, "window = one 16-wide register vector + the newest frame in a scalar slot");
-  typedef float v16f __attribute__((ext_vector_type(16)));
+  static_assert(FL >= 3 && 2 * (FL - 1) <= CVVDP_ROT_NEW, "window = one 16- or 32-wide register vector + the newest frame in a scalar slot");
+  typedef float v16f __attribute__((ext_vector_type(FL <= 17 ? 16 : 32)));
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= a.P) return;
   const int b = blockIdx.y, side = blockIdx.z;
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
       const float* t = tb + c * CVVDP_ROT_TAPS;                                                                  \
       float acc = 0.0f;                                                                                          \
       _Pragma("unroll") for (int s = 0; s < M; ++s) acc += wlo[p][s] * t[s];                                     \
-      acc += whi[p] * a.taps_rot[c * CVVDP_ROT_TAPS + 32];                                                       \
+      acc += whi[p] * a.taps_rot[c * CVVDP_ROT_TAPS + CVVDP_ROT_NEW];                                            \
       CVVDP_FIR_STORE(acc, &out[(int64_t)(2 * c + side) * a.o_plane + (int64_t)(FI) * o_item]);                \
     }                                                                                                            \
     sA = (sA + 1 == M) ? 0 : sA + 1;                                                                             \
@@ -429,7 +430,7 @@ static void launch_fused(const FirArgs& a, hipStream_t s) {
   {
     dim3 grid((a.P + 255) / 256, a.batch, 2);
     static const bool rot = dev_knob("CVVDP_FIR_ROT", 1) != 0;
-    if constexpr (FL <= 17) {
+    if constexpr (2 * (FL - 1) <= CVVDP_ROT_NEW) {
       if (rot) { hipLaunchKernelGGL((k_fir_rot<DT, FL>), grid, dim3(256), 0, s, a); return; }
     }
     hipLaunchKernelGGL((k_fir_fused<DT, FL, 1>), grid, dim3(256), 0, s, a);

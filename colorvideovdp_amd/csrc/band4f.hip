@@ -60,9 +60,23 @@ __device__ __forceinline__ void f_lds_write4(float* p, const float (&v)[4]) {
 // columns right of the image become the reduce's zero padding), it owns ONE coarse column (the last one: the first / last column
 // rule moves from the lane's second coarse column to its first), stores one level-(l+1) sample instead of two, the blur's reflect
 // padding is written column by column, and its two columns outside the image are masked out of the pooling.
-template <int NCH, int EDGE>
-__global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
+//
+// HEAT: the level's heat-map band as well (band4.hip, HEAT): the channel's term in the pooling stage, the channel norm one column per
+// thread a barrier later.  The border instantiations have no registers for it (54 / 16 spilled VGPRs, profiles/r03_dev_notes.txt 17), and
+// a spill reload among hand-issued loads breaks their wait counts: the HEAT instantiations therefore use ordinary loads the compiler
+// tracks itself (F_SAFE).  They are slower per strip, and they are the two or three border strips of a level only -- the other
+// strips run k_band4s<HEAT> (band4s.hip) beside them.
+struct __attribute__((packed, aligned(4))) f_u4 { float x, y, z, w; };     // (rows of W % 4 == 2 frames are 8-byte aligned)
+struct __attribute__((packed, aligned(4))) f_u2 { float x, y; };
+
+template <int NCH, int EDGE, bool HEAT>
+__device__ __forceinline__ void band4f_body(const BandArgs& a) {
   constexpr bool RAG = EDGE == 2;
+#ifdef CVVDP_SAFE_LOADS
+  constexpr bool F_SAFE = true;       // `make safe`: every instantiation (tests/test_safe_loads.py)
+#else
+  constexpr bool F_SAFE = HEAT;
+#endif
   constexpr int NP = 2 * NCH;
   __shared__ __attribute__((aligned(16))) float2 s_ve[2][NP][F_VE / 2];
   __shared__ __attribute__((aligned(16))) float s_lum[2][256];            // 1/L_T, 1/L_R
@@ -71,6 +85,7 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   __shared__ __attribute__((aligned(16))) float s_q[NCH][256];
   __shared__ __attribute__((aligned(16))) float s_d[F_R + 1][NCH][F_SW];  // lane-private ring of |T'-R'| + eps
   __shared__ __attribute__((aligned(8))) float2 s_lut[NCH][CVVDP_CSF_NODES];
+  __shared__ __attribute__((aligned(16))) float s_h[HEAT ? NCH : 1][HEAT ? 256 : 4];   // heat-map terms of the pooled row, per channel
 
   const int t = threadIdx.x;
   const int c = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -317,12 +332,28 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
       const v2f T = X * inv_dmax + M1;
       const float r0 = fast_rcp(T.x), r1 = fast_rcp(T.y);
       De[2 * h] = __builtin_fmaf(X.x, r0, kEps); De[2 * h + 1] = __builtin_fmaf(X.y, r1, kEps);
+      if constexpr (HEAT) {   // this channel's term of the per-pixel channel norm (cvvdp_metric.py:728-734; band4.hip stage3c)
+        s_h[c][4 * j + 2 * h] = fast_pow((X.x * r0) * a.hw[c] + kEps, a.beta_tch) - a.eps_btch;
+        s_h[c][4 * j + 2 * h + 1] = fast_pow((X.y * r1) * a.hw[c] + kEps, a.beta_tch) - a.eps_btch;
+      }
     }
     if constexpr (RAG) {
       if (part) { De[2] = 0.0f; De[3] = 0.0f; }                        // columns right of the image do not exist: no term
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc = __builtin_fmaf(De[i], De[i], acc);   // sum of (D + eps)^2; k_finalize takes the eps^2 off
+  };
+  // heat-map band of row y from the channel terms published by stage3c (a barrier in between): one column per thread, lp_norm over
+  // the channels, stored / band_mul as lpyr_dec_2.set_lband does (lpyr_dec.py:308-314; band4.hip heat_row)
+  auto heat_row = [&](int y) {
+    if constexpr (HEAT) {
+      const int xs = x0 - F_HALO + t;
+      if (y >= ys && t >= F_HALO && t < 256 - F_HALO && xs < W) {
+        float sum = s_h[0][t] + s_h[1][t] + s_h[2][t];
+        if constexpr (NCH == 4) sum += s_h[3][t];
+        a.dchr[(int64_t)item * P + (int64_t)y * W + xs] = (fast_pow(sum + kEps, 1.0f / a.beta_tch) - a.eps_inv_btch) / a.band_mul;
+      }
+    }
   };
 
   // ---- STREAM LOADS (see band4.hip): issued from inline assembly, waited for with one exact count per step.
@@ -336,24 +367,16 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   for (int i = 0; i < 8; ++i) { ringT[i] = 0.0f; ringR[i] = 0.0f; }
 #pragma unroll
   for (int i = 0; i < 2; ++i) { nbLT[i] = 0.0f; nbLR[i] = 0.0f; nbRT[i] = 0.0f; nbRR[i] = 0.0f; }
-#ifdef CVVDP_SAFE_LOADS
-  // `make safe`: the same kernel with ordinary loads the compiler tracks and waits for itself (the dynamic check of the hand-managed ones,
-  // tests/test_safe_loads.py)
+  // F_SAFE (`make safe`, and the HEAT instantiations): ordinary loads the compiler tracks and waits for itself
 #define F_ROWPTR(plane, row, off) (reinterpret_cast<const char*>((plane) + (int64_t)(row) * W) + (off))
-  struct __attribute__((packed, aligned(4))) u4 { float x, y, z, w; };     // (rows of W % 4 == 2 frames are 8-byte aligned)
-  struct __attribute__((packed, aligned(4))) u2 { float x, y; };
-#define F_LOAD4(dst, off, plane, row) do { const u4 q_ = *reinterpret_cast<const u4*>(F_ROWPTR(plane, row, off)); dst = v4f{q_.x, q_.y, q_.z, q_.w}; } while (0)
-#define F_LOAD2(dst, off, plane, row) do { const u2 q_ = *reinterpret_cast<const u2*>(F_ROWPTR(plane, row, off)); dst = v2f{q_.x, q_.y}; } while (0)
-#define F_LOAD1(dst, off, plane, row) dst = *reinterpret_cast<const float*>(F_ROWPTR(plane, row, off))
-#define F_WAIT2(...) do { } while (0)
-#define F_DRAIN() do { } while (0)
-#else
-#define F_LOAD4(dst, off, plane, row) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W))
-#define F_LOAD2(dst, off, plane, row) asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W))
-#define F_LOAD1(dst, off, plane, row) asm volatile("global_load_dword %0, %1, %2" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W))
-#define F_WAIT2(a0, a1, a2, a3, a4, a5) asm volatile("s_waitcnt vmcnt(2)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5))
-#define F_DRAIN() do { __builtin_amdgcn_s_waitcnt(0x0F70); } while (0)
-#endif
+#define F_LOAD4(dst, off, plane, row) do { if constexpr (F_SAFE) { const f_u4 q_ = *reinterpret_cast<const f_u4*>(F_ROWPTR(plane, row, off)); dst = v4f{q_.x, q_.y, q_.z, q_.w}; } \
+    else asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W)); } while (0)
+#define F_LOAD2(dst, off, plane, row) do { if constexpr (F_SAFE) { const f_u2 q_ = *reinterpret_cast<const f_u2*>(F_ROWPTR(plane, row, off)); dst = v2f{q_.x, q_.y}; } \
+    else asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W)); } while (0)
+#define F_LOAD1(dst, off, plane, row) do { if constexpr (F_SAFE) dst = *reinterpret_cast<const float*>(F_ROWPTR(plane, row, off)); \
+    else asm volatile("global_load_dword %0, %1, %2" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W)); } while (0)
+#define F_WAIT2(a0, a1, a2, a3, a4, a5) do { if constexpr (!F_SAFE) asm volatile("s_waitcnt vmcnt(2)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5)); } while (0)
+#define F_DRAIN() do { if constexpr (!F_SAFE) __builtin_amdgcn_s_waitcnt(0x0F70); } while (0)
   auto rowc = [&](int r) { return min(max(r, 0), H - 1); };       // rows outside the image: any valid row (their weight is 0)
 
   // image-edge mirror roles of the contrast stage (band4.hip): reflect padding of the blur at the left / right image border
@@ -463,6 +486,7 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
     coarse_finish(ODD ? 0 : 1, std::integral_constant<bool, !ODD>{}, ODD, emitted);   // vertical expand of row r+1
     __syncthreads();
     // ================= phase 2
+    heat_row(yprev);
     {
       const int r6 = rowc(r + 6), r7 = rowc(r + 7);
       F_LOAD2(nbLT[U & 1], loff, gT, r6);                           // (r + 6) & 1 == U & 1
@@ -525,6 +549,7 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
     const int yprev = r - 1 - F_R;
     if (interior && yprev >= ys) stage3c(k7);
     __syncthreads();
+    heat_row(yprev);
     const int yc = r - F_R;
     if (interior) {
       const int back = 2 * (r - (H - 1));                           // 2, 4, .. 12 rows back
@@ -580,6 +605,10 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
   for (r = rreal; r < rend; ++r) tail_step(r);
   // ---- epilogue: pooling stage of the last centre row
   if (interior && (ye - 1) >= ys) stage3c(k7);
+  if constexpr (HEAT) {
+    __syncthreads();
+    heat_row(ye - 1);
+  }
 
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -594,9 +623,12 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) {
 #undef F_LOAD1
 #undef F_DRAIN
 #undef F_WAIT2
-#ifdef CVVDP_SAFE_LOADS
 #undef F_ROWPTR
-#endif
+
+template <int NCH, int EDGE>
+__global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) { band4f_body<NCH, EDGE, false>(a); }
+template <int NCH, int EDGE>
+__global__ __launch_bounds__(64 * NCH, 2) void k_band4f_heat(BandArgs a) { band4f_body<NCH, EDGE, true>(a); }
 
 bool band4f_supported(int H, int W) { return (W & 1) == 0 && W >= 32 && H >= 32; }
 
@@ -612,12 +644,19 @@ void launch_band4f(const BandArgs& a0, hipStream_t s, hipStream_t s_edge) {
   const int n_edge = std::min(a.n_strip, 1 + band4f_right_edge_strips(a.W, a.n_strip));   // strip 0 + the right-edge strips
   a.strip0 = 0; a.n_strip_l = n_edge;
   a.per_xcd = (a.n_strip_l * a.n_seg * a.items + 7) / 8;
-  if ((a.W & 3) == 0) hipLaunchKernelGGL((k_band4f<4, 1>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);     // video only (core.cpp)
-  else hipLaunchKernelGGL((k_band4f<4, 2>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);
+  const bool heat = a.dchr != nullptr;
+  if (heat) {
+    if ((a.W & 3) == 0) hipLaunchKernelGGL((k_band4f_heat<4, 1>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);
+    else hipLaunchKernelGGL((k_band4f_heat<4, 2>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);
+  } else {
+    if ((a.W & 3) == 0) hipLaunchKernelGGL((k_band4f<4, 1>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);     // video only (core.cpp)
+    else hipLaunchKernelGGL((k_band4f<4, 2>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);
+  }
   if (n_edge < a.n_strip) {
     a.strip0 = 1; a.n_strip_l = a.n_strip - n_edge;
     a.per_xcd = (a.n_strip_l * a.n_seg * a.items + 7) / 8;
-    if (a.one_wave_layout) hipLaunchKernelGGL((k_band4f<4, 0>), dim3(8 * a.per_xcd), dim3(256), 0, s, a);
+    if (a.one_wave_layout && heat) hipLaunchKernelGGL((k_band4f_heat<4, 0>), dim3(8 * a.per_xcd), dim3(256), 0, s, a);
+    else if (a.one_wave_layout) hipLaunchKernelGGL((k_band4f<4, 0>), dim3(8 * a.per_xcd), dim3(256), 0, s, a);
     else launch_band4s(a, s);
   }
 }

@@ -16,8 +16,9 @@
 // chain is half as long and three other waves stand by.  Same two barriers per row; per-row hand-offs are double-buffered by row
 // parity (s_ve, s_g).  LDS: 65.8 KB per block (k_band4f: 50) -- two blocks per CU fit the 160 KB.
 //
-// The arithmetic is k_band4f<4, 0>'s, operation for operation (same FMA chains, same order): the two kernels' partial sums and
-// level-(l+1) planes are bit-identical (tests/test_gpu_parity.py::test_split_band_kernel_matches_the_one_wave_layout).  Only the strips away from the
+// The arithmetic is k_band4f<4, 0>'s, operation for operation (same FMA chains, same order): the two kernels' level-(l+1) planes are
+// bit-identical and their partial sums agree to the last bit -- they are two separately compiled kernels, and the compiler contracts a
+// multiply-add here and not there (tests/test_gpu_parity.py::test_split_band_kernel_matches_the_one_wave_layout).  Only the strips away from the
 // image's left / right border run here (EDGE = 0 of band4f.hip); the border strips keep k_band4f<4, 1 / 2> on the edge stream.
 // Reference arithmetic: lpyr_dec.py:186-239,386-408, cvvdp_metric.py:835-856,945-950,963-971 (see band4.hip / band4f.hip).
 #include <type_traits>
@@ -62,8 +63,12 @@ __device__ __forceinline__ void s_for_seq(F&& f, std::integer_sequence<int, Us..
 #define S_SYNC() __syncthreads()
 #endif
 
-__global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
+// HEAT: the level's heat-map band as well (band4.hip, HEAT): the back waves publish their channel's term of the pooled row, and one
+// barrier later the 256 back threads take one column each (lp_norm over the channels).
+template <bool HEAT>
+__device__ __forceinline__ void band4s_body(const BandArgs& a) {
   constexpr int NCH = 4, NP = 8;
+  __shared__ __attribute__((aligned(16))) float s_h[HEAT ? NCH : 1][HEAT ? 256 : 4];   // heat-map terms of the pooled row, per channel
   __shared__ __attribute__((aligned(16))) float2 s_ve[2][NP][S_VE / 2];
   __shared__ __attribute__((aligned(16))) float s_g[2][NP][256];             // raw level-l row handed from the front to the back (by row parity)
   __shared__ __attribute__((aligned(16))) float s_lum[2][256];               // 1/L_T, 1/L_R
@@ -373,6 +378,7 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
       S_SYNC();
       S_SYNC();
     }
+    if constexpr (HEAT) __syncthreads();      // (the back's epilogue: channel terms of the last pooled row -> its heat-map band)
 #undef S_LOAD4
 #undef S_LOADL
 #undef S_LOADR
@@ -394,6 +400,7 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
     const float xw0 = a.xw[0 * 4 + c], xw1 = a.xw[1 * 4 + c], xw2 = a.xw[2 * 4 + c], xw3 = a.xw[3 * 4 + c];
     const float m1c = a.m1[c];
     const float inv_dmax = a.inv_dmax;
+    const float hw_c = a.hw[c], beta_tch = a.beta_tch, eps_btch = a.eps_btch, inv_beta_tch = 1.0f / a.beta_tch, eps_inv_btch = a.eps_inv_btch;
 
     // horizontal half of the expand for this lane's 4 columns from 4 coarse values (lpyr_dec.py:234-237)
     auto expand4 = [&](const float2* row, float (&ex)[4]) {
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
       const sf4 q0 = s_lds_read4(&s_q[0][4 * j]), q1 = s_lds_read4(&s_q[1][4 * j]), q2 = s_lds_read4(&s_q[2][4 * j]);
       const sf4 q3 = s_lds_read4(&s_q[3][4 * j]);
       const sf4 d = s_lds_read4(&s_d[k7][c][4 * j - S_HALO]);
-      float De[4];
+      float De[4], Dh[4];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const v2f Q0 = {q0.v[2 * h], q0.v[2 * h + 1]}, Q1 = {q1.v[2 * h], q1.v[2 * h + 1]}, Q2 = {q2.v[2 * h], q2.v[2 * h + 1]}, Q3 = {q3.v[2 * h], q3.v[2 * h + 1]};
@@ -437,9 +444,27 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
         const v2f T = X * inv_dmax + M1;
         const float r0 = fast_rcp(T.x), r1 = fast_rcp(T.y);
         De[2 * h] = __builtin_fmaf(X.x, r0, kEps); De[2 * h + 1] = __builtin_fmaf(X.y, r1, kEps);
+        if constexpr (HEAT) { Dh[2 * h] = X.x * r0; Dh[2 * h + 1] = X.y * r1; }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc = __builtin_fmaf(De[i], De[i], acc);   // sum of (D + eps)^2; k_finalize takes the eps^2 off
+      if constexpr (HEAT) {   // this channel's term of the per-pixel channel norm (cvvdp_metric.py:728-734; band4.hip stage3c)
+        float ht[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ht[i] = fast_pow(Dh[i] * hw_c + kEps, beta_tch) - eps_btch;
+        s_lds_write4(&s_h[c][4 * j], ht);
+      }
+    };
+    // heat-map band of row y from the channel terms published by stage3c (a barrier in between): one column per back thread, lp_norm
+    // over the channels, stored / band_mul as lpyr_dec_2.set_lband does (lpyr_dec.py:308-314; band4.hip heat_row)
+    auto heat_row = [&](int y) {
+      if constexpr (HEAT) {
+        const int col = t - 64 * NCH;
+        if (y >= ys && col >= S_HALO && col < 256 - S_HALO) {
+          const float sum = (s_h[0][col] + s_h[1][col] + s_h[2][col]) + s_h[3][col];
+          a.dchr[(int64_t)item * ((int64_t)H * W) + (int64_t)y * W + (x0 - S_HALO + col)] = (fast_pow(sum + kEps, inv_beta_tch) - eps_inv_btch) / a.band_mul;
+        }
+      }
     };
     // vertical 13-tap blur of the window -> Mq = (blur + eps)^q -> s_q; then the weights rotate
     auto vblur = [&](int yc) {
@@ -520,6 +545,7 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
       }
       S_SYNC();
       // ================= phase 2
+      heat_row(yprev);
       vblur(r - S_R);
       slot = slot == S_BW - 1 ? 0 : slot + 1;
       k7 = k7 == S_R ? 0 : k7 + 1;
@@ -530,6 +556,7 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
       const int yprev = r - 1 - S_R;
       if (interior && yprev >= ys) stage3c(k7);
       S_SYNC();
+      heat_row(yprev);
       if (interior) {
         const int back = 2 * (r - (H - 1));                           // 2, 4, .. 12 rows back
         const int src = slot >= back ? slot - back : slot - back + S_BW;
@@ -551,6 +578,10 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
     for (r = rreal; r < rend; ++r) tail_step(r);
     // ---- epilogue: pooling stage of the last centre row
     if (interior && (ye - 1) >= ys) stage3c(k7);
+    if constexpr (HEAT) {
+      __syncthreads();
+      heat_row(ye - 1);
+    }
 
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -562,9 +593,13 @@ __global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) {
 #endif
 }
 
+__global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) { band4s_body<false>(a); }
+__global__ __launch_bounds__(512, 4) void k_band4s_heat(BandArgs a) { band4s_body<true>(a); }
+
 // the strips away from the image's left / right border of a fused level (launch_band4f deals them: strip0 .. strip0 + n_strip_l - 1)
 void launch_band4s(const BandArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_band4s, dim3(8 * a.per_xcd), dim3(512), 0, s, a);
+  if (a.dchr) hipLaunchKernelGGL(k_band4s_heat, dim3(8 * a.per_xcd), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL(k_band4s, dim3(8 * a.per_xcd), dim3(512), 0, s, a);
 }
 
 }  // namespace cvvdp

@@ -988,8 +988,10 @@ def test_split_band_kernel_matches_the_one_wave_layout(W, H, F, fps, disp):
     assert runs[0][3] == runs[1][3] >= 1
     for l, (a, b) in enumerate(zip(runs[0][2], runs[1][2])):
         np.testing.assert_array_equal(a, b, err_msg=f"pyramid level {l}")
-    np.testing.assert_array_equal(runs[0][1], runs[1][1])
-    assert runs[0][0] == runs[1][0]
+    # the per-frame sums: the same chain of operations in two separately compiled kernels -- the compiler contracts a multiply-add here
+    # and not there, so single values may differ in the last bit (observed: one of 64 by one ulp); a clip is scored by ONE layout
+    np.testing.assert_allclose(runs[0][1], runs[1][1], rtol=3e-7, atol=0)
+    assert abs(runs[0][0] - runs[1][0]) < 2e-6
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -1075,3 +1077,33 @@ def test_device_heatmap_sink_gets_the_same_frames_without_pcie():
         else:
             assert torch.equal(torch.cat([x for _, x in seen], 2).cpu(), full["heatmap"])
         np.testing.assert_array_equal(st["Q_per_ch"], full["Q_per_ch"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Heat-map clips on the fused band kernels (k_band4s_heat / k_band4f_heat): the band kernel computes the next level AND the level's
+# heat-map band.  Against the unfused route: same heat map to fp16 rounding; between the two wave layouts: the same bits.
+@pytest.mark.parametrize("W,H,F,fps,disp,mode", [
+    (1200, 144, 3, 60, "standard_4k", "supra-threshold"),      # five strips, three on the split kernel
+    (736, 416, 4, 30, "standard_fhd", "threshold"),            # several row segments
+    (1446, 333, 2, 60, "standard_hdr_pq", "raw"),              # W % 4 == 2: partial-lane border kernel, odd height
+])
+def test_fused_band_kernels_write_the_heat_map_bands(W, H, F, fps, disp, mode):
+    import colorvideovdp_amd as cv
+    t, r = _fuse_clip(W, H, F, W + 3 * H)
+    t, r = torch.as_tensor(t).cuda(), torch.as_tensor(r).cuda()
+    runs = {}
+    for name, fuse_mode, layout in (("unfused", 2, 0), ("split", 1, 0), ("one_wave", 1, 1)):
+        m = cv.cvvdp(display_name=disp, heatmap=mode)
+        m.fuse_mode, m.band_layout = fuse_mode, layout
+        jod, st = m.predict(t, r, dim_order="BCFHW", frames_per_second=fps)
+        assert (m.fused_levels >= 1) == (fuse_mode == 1)
+        runs[name] = (float(jod), st["Q_per_ch"], st["heatmap"].clone())
+    assert abs(runs["split"][0] - runs["one_wave"][0]) < 2e-6
+    np.testing.assert_allclose(runs["split"][1], runs["one_wave"][1], rtol=3e-7, atol=0)
+    dl = (runs["split"][2].float() - runs["one_wave"][2].float()).abs()
+    assert float(dl.max()) <= 1e-3 and float((dl > 0).float().mean()) < 1e-3      # (fp16 codes; the last-bit caveat of the test above)
+    assert abs(runs["split"][0] - runs["unfused"][0]) < 1e-4
+    np.testing.assert_allclose(runs["split"][1], runs["unfused"][1], rtol=5e-5, atol=5e-7)       # (test_fused_reduce_band_kernels' bound)
+    d = (runs["split"][2].float() - runs["unfused"][2].float()).abs()
+    # the two routes round the pyramid differently in the last bit; the map is fp16: a handful of pixels land on a neighbouring code
+    assert float(d.max()) <= 2e-3 and float((d > 0).float().mean()) < 0.02, (float(d.max()), float((d > 0).float().mean()))

@@ -286,6 +286,47 @@ def measured_copy_ceiling():
     return {"GBs": best * 1e3, "source": "profiles/" + os.path.basename(files[-1]) + " (best float4 copy of the sweep)"} if best > 0 else None
 
 
+def power_probe(step, sync, seconds=1.6):
+    """Shader clock and socket power while the step runs back to back (untimed, after the timed region): `rocm-smi --showclocks
+    --showpower --json` sampled in a side thread.  The 4K step runs at the socket's power limit (profiles/r04_dev_notes.txt 4): the
+    clock it is allowed, not the 2.4 GHz of the data sheet, is what the VALU-issue bound of the band kernels has to be priced at.
+    Returns None where rocm-smi is missing or prints something else."""
+    import subprocess
+    import threading
+    samples, stop = [], [False]
+
+    def sampler():
+        while not stop[0]:
+            try:
+                txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+                card = next(iter(json.loads(txt).values()))
+                sclk = next(v for k, v in card.items() if k.lower().startswith("sclk clock speed"))
+                watts = next(v for k, v in card.items() if "power" in k.lower() and "(w)" in k.lower())
+                samples.append((time.perf_counter(), float(str(sclk).strip("()MmHhZz")), float(watts)))
+            except Exception:      # noqa
+                return
+            time.sleep(0.03)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        step()
+        n += 1
+    sync()
+    t1 = time.perf_counter()
+    stop[0] = True
+    th.join(timeout=6)
+    use = [s for s in samples if t0 + 0.6 <= s[0] <= t1]          # power and clock settle within ~0.4 s of load
+    if len(use) < 3:
+        return None
+    return {"sclk_MHz_under_load": round(sum(s[1] for s in use) / len(use), 1), "socket_W_under_load": round(sum(s[2] for s in use) / len(use), 1),
+            "samples": len(use), "steps_run": n, "sclk_MHz_peak": 2400.0,
+            "note": "rocm-smi beside an untimed loop of the same step, first 0.6 s dropped; the step draws the socket's power limit and the "
+                    "shader clock is what that limit leaves (the guide's VALU peak assumes 2.4 GHz)"}
+
+
 def lockstep_spinup(step, seconds, world, flag_device, sync=lambda: None, collective=None):
     """Untimed spin-up: run step() for about `seconds`, the SAME number of times on every rank.  Multi-rank, every step() ends in
     a collective (the all-gather of Q_per_ch), so a per-rank clock must not decide when to stop: ranks enter the loop at different
@@ -330,6 +371,7 @@ def main():
     ap.add_argument("--fps", type=int, default=None, help="override the workload's frame rate (e.g. 120: 31-tap temporal filters, k_fir_fused)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU baseline sample: a prefix of the workload clip (SURVEY 8d: 16; 0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip the 1.6 s of untimed steps under rocm-smi after the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -423,6 +465,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = None if args.no_profile else m.profile_read()
     m.profile(False)
+    power = power_probe(step, torch.cuda.synchronize) if (world == 1 and not args.no_profile and not args.no_power_probe) else None
     if dist_on:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -440,7 +483,7 @@ def main():
     else:
         what += f", {n_total}-frame clip pair"
     if heat is not None:
-        what += f", {heat} heat map streamed to the host in blocks"
+        what += f", {heat} heat map " + ("streamed to the host in blocks" if args.heatmap_sink == "host" else "consumed on the GPU in blocks")
     out = {
         "metric": "Mpixels/s", "value": round(mpix, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
@@ -506,8 +549,8 @@ def main():
                 traffic = (ktraffic or {}).get("band_level0", {}).get("hbm_bytes_per_launch")
                 traffic_note = ("FETCH_SIZE x 2 + WRITE_SIZE per launch from separate --pmc passes over these kernel sources (stamp matches; "
                                 f"library binary {'identical' if have.get('lib_sha256') == stamp['lib_sha256'] else 'rebuilt from the same sources'})")
-        out["roofline"] = {"bound": "hbm", "kernel": ("k_band4f<4> level 0 (5x5 reduce to level 1 + expand/contrast/CSF/masking/blur/pooling; border strips as a "
-                                                      "second launch beside the others: the pair is timed)") if fused_levels > 0 else
+        out["roofline"] = {"bound": "hbm", "kernel": ("k_band4s level 0 (front waves: ring, 5x5 reduce to level 1, expand, luminance terms; back waves: contrast, CSF, masking, "
+                                                      "blurs, pooling) + k_band4f<4, 1> on the border strips as a second launch beside it: the pair is timed") if fused_levels > 0 else
                                                      "k_band4<4> level 0 (fused expand/contrast/CSF/masking/blur/pooling)",
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "traffic_note": traffic_note, "avg_launch_ms": round(avg_ms, 4), "launches": n,
@@ -518,7 +561,7 @@ def main():
             # "bound": "hbm" above is the accounting the bench contract asks for, not a claim that HBM limits it
             out["roofline"]["valu"] = {"busy": sq.get("valu_busy"), "instructions_per_launch": sq.get("valu_instructions_per_launch"),
                                        "waves_waiting_frac": sq.get("waves_waiting_frac"), "workgroups": sq.get("workgroups"),
-                                       "source": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32), profiles/r03_pmc_sq_counters.txt"}
+                                       "source": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32), profiles/*_pmc_sq_counters.txt (tools/sq_counters.sh)"}
         # the other two dominant kernels on the same footing (algorithmic bytes per step / HIP-event time per step / 8 TB/s)
         px_step = W * H * count
         in_b = INPUT_BYTES_PER_PIXEL[dtype]
@@ -539,6 +582,16 @@ def main():
                 out["path_roofline"]["valu_issue"] = tj["step_valu"]
                 if "valu" in out["roofline"]:
                     out["roofline"]["valu"]["frac_of_issue"] = out["roofline"]["valu"].get("busy")
+        if power is not None:
+            out["power"] = power
+            v = out["roofline"].get("valu")
+            if v and v.get("instructions_per_launch") and ktraffic:
+                # the band kernels' other bound, at the clock the power limit leaves: VALU quad-cycles of the launch pair / 1024 SIMDs
+                quad = sum(s.get("valu_quad_cycles", 0) for s in ((ktraffic.get("band_level0") or {}).get("sq_all") or []))
+                if quad > 0:
+                    bound_ms = quad * 4 / 1024 / (power["sclk_MHz_under_load"] * 1e3)
+                    v["issue_bound_ms_at_load_clock"] = round(bound_ms, 3)
+                    v["frac_of_issue_bound_at_load_clock"] = round(bound_ms / avg_ms, 4)
         tot = sum(v[0] for v in prof.values())
         out["kernel_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in prof.items()}
         out["kernel_ms_per_step"]["sum"] = round(tot / args.steps, 3)

@@ -79,7 +79,7 @@ void launch_fir(const FirArgs& a, float* hist_shadow, hipStream_t) {
   REQUIRE(a.n_frames >= 1 && a.fl - 1 + a.n_frames <= CVVDP_MAX_WINDOW, "fir: window %d + %d", a.fl - 1, a.n_frames);
   const int kl = fir_kernel_len(a.fl);
   REQUIRE(kl >= a.fl && kl <= CVVDP_MAX_FILTER_LEN, "fir: kernel length %d for fl %d", kl, a.fl);
-  if (kl <= 17) REQUIRE(2 * (kl - 1) <= 32, "fir: rotating tap table of %d entries per channel", 2 * (kl - 1));
+  if (kl <= 31) REQUIRE(2 * (kl - 1) <= CVVDP_ROT_NEW, "fir: rotating tap table of %d entries per channel", 2 * (kl - 1));
   in_ws(a.out, 7 * (size_t)a.o_plane + (size_t)a.n_frames * a.batch * a.P, "fir level-0 planes");
   bool uses_hist = a.write_hist != 0;
   for (int k = 0; k < a.fl - 1; ++k) {
@@ -98,31 +98,32 @@ static void chk_reduce_geom(int H, int W, int Ho, int Wo, const char* what) {
 }
 void launch_reduce(const ReduceArgs& a, hipStream_t) {
   ++g_launches; chk_reduce_geom(a.H, a.W, a.Ho, a.Wo, "reduce");
-  REQUIRE(a.n_img <= a.img_cap, "reduce: %d images of %d", a.n_img, a.img_cap);
-  in_ws(a.in, (size_t)a.n_planes * a.img_cap * a.H * a.W, "reduce in");
-  in_ws(a.out, (size_t)a.n_planes * a.img_cap * a.Ho * a.Wo, "reduce out");
+  REQUIRE(a.n_img <= a.img_cap && a.n_img <= a.img_cap_out, "reduce: %d images of %d -> %d", a.n_img, a.img_cap, a.img_cap_out);
+  in_ws(a.in, ((size_t)(a.n_planes - 1) * a.img_cap + a.n_img) * a.H * a.W, "reduce in");       // (level 0 of a clip scored in pieces: a.in points at the piece)
+  in_ws(a.out, (size_t)a.n_planes * a.img_cap_out * a.Ho * a.Wo, "reduce out");
 }
 bool reduce2_supported(int H, int W) { return (W % 16 == 0 || W >= 32) && H >= 8; }   // (mirror of pyramid.hip)
 void launch_reduce2(const Reduce2Args& a, hipStream_t) {
   ++g_launches; chk_reduce_geom(a.H, a.W, a.H1, a.W1, "reduce2 l+1"); chk_reduce_geom(a.H1, a.W1, a.H2, a.W2, "reduce2 l+2");
   REQUIRE(reduce2_supported(a.H, a.W), "reduce2 launched on %dx%d", a.W, a.H);
-  in_ws(a.in, (size_t)a.n_planes * a.img_cap * a.H * a.W, "reduce2 in");
-  in_ws(a.out1, (size_t)a.n_planes * a.img_cap * a.H1 * a.W1, "reduce2 out1");
-  in_ws(a.out2, (size_t)a.n_planes * a.img_cap * a.H2 * a.W2, "reduce2 out2");
+  REQUIRE(a.n_img <= a.img_cap && a.n_img <= a.img_cap_out, "reduce2: %d images of %d -> %d", a.n_img, a.img_cap, a.img_cap_out);
+  in_ws(a.in, ((size_t)(a.n_planes - 1) * a.img_cap + a.n_img) * a.H * a.W, "reduce2 in");
+  in_ws(a.out1, (size_t)a.n_planes * a.img_cap_out * a.H1 * a.W1, "reduce2 out1");
+  in_ws(a.out2, (size_t)a.n_planes * a.img_cap_out * a.H2 * a.W2, "reduce2 out2");
 }
 
 static void chk_band(const BandArgs& a, int strip_w, const char* what) {
   ++g_launches;
   const size_t P = (size_t)a.H * a.W, Pc = (size_t)a.Hc * a.Wc;
   REQUIRE(a.nch == 3 || a.nch == 4, "%s: nch %d", what, a.nch);
-  REQUIRE(a.items >= 1 && a.items <= a.items_cap, "%s: %d items of %d", what, a.items, a.items_cap);
+  REQUIRE(a.items >= 1 && a.items <= a.items_cap && a.items <= a.items_cap_c, "%s: %d items of %d / %d", what, a.items, a.items_cap, a.items_cap_c);
   REQUIRE(a.Hc == (a.H + 1) / 2 && a.Wc == (a.W + 1) / 2, "%s: coarse level %dx%d of %dx%d", what, a.Wc, a.Hc, a.W, a.H);
   REQUIRE((int64_t)a.n_strip * strip_w >= a.W && (int64_t)(a.n_strip - 1) * strip_w < a.W, "%s: %d strips of %d over W %d", what, a.n_strip, strip_w, a.W);
   REQUIRE((int64_t)a.n_seg * a.seg_h >= a.H && (int64_t)(a.n_seg - 1) * a.seg_h < a.H, "%s: %d segments of %d rows over H %d", what, a.n_seg, a.seg_h, a.H);
-  in_ws(a.g, 2 * (size_t)a.nch * a.items_cap * P, "band g");
-  in_ws(a.gc, 2 * (size_t)a.nch * a.items_cap * Pc, "band gc");
+  in_ws(a.g, ((size_t)(2 * a.nch - 1) * a.items_cap + a.items) * P, "band g");       // (level 0 of a clip scored in pieces: a.g points at the piece)
+  in_ws(a.gc, 2 * (size_t)a.nch * a.items_cap_c * Pc, "band gc");
   in_ws(a.partial, (size_t)a.items * a.n_strip * a.n_seg * 4, "band partial sums");
-  if (a.dchr) in_ws(a.dchr, (size_t)a.items_cap * P, "band heat band");
+  if (a.dchr) in_ws(a.dchr, (size_t)a.items * P, "band heat band");
   if (a.ddump) in_ws(a.ddump, 4 * (size_t)a.items_cap * P, "band D dump");
   if (a.fdump) in_ws(a.fdump, 8 * (size_t)a.items_cap * P, "band |T'|,|R'| planes");
   if (a.fsum) {
@@ -148,17 +149,17 @@ bool band4f_supported(int H, int W) { return (W & 1) == 0 && W >= 32 && H >= 32;
 void launch_band4f(const BandArgs& a, hipStream_t, hipStream_t) {
   chk_band(a, kBand4StripWidth, "k_band4f");
   REQUIRE(band4f_supported(a.H, a.W) && a.nch == 4 && a.seg_h % 2 == 0 && a.seg_h >= 8, "k_band4f on %dx%d, %d channels, seg_h %d", a.W, a.H, a.nch, a.seg_h);
-  REQUIRE(!a.dchr && !a.ddump && !a.fdump && !a.fsum, "k_band4f with a heat map / dump / features buffer");
-  in_ws(a.g1_out, 2 * (size_t)a.nch * a.items_cap * a.Hc * a.Wc, "k_band4f level l+1 planes");
+  REQUIRE(!a.ddump && !a.fdump && !a.fsum, "k_band4f with a dump / features buffer");       // (a heat-map band: the HEAT instantiations)
+  in_ws(a.g1_out, 2 * (size_t)a.nch * a.items_cap_c * a.Hc * a.Wc, "k_band4f level l+1 planes");
   REQUIRE(a.g1_out == a.gc, "k_band4f writes another buffer than the next level's planes");
 }
 void launch_baseband(const BaseArgs& a, hipStream_t) {
   ++g_launches;
   const size_t P = (size_t)a.H * a.W;
-  in_ws(a.g, 2 * (size_t)a.nch * a.items_cap * P, "baseband g");
+  in_ws(a.g, ((size_t)(2 * a.nch - 1) * a.items_cap + a.items) * P, "baseband g");
   REQUIRE(a.level == a.q_levels - 1 && a.q_frame_offset + a.items / a.batch <= a.q_frames, "baseband: Q window");
   in_ws(a.q_out, (size_t)a.batch * a.nch * a.q_frames * a.q_levels, "baseband Q_per_ch");
-  if (a.dchr) in_ws(a.dchr, (size_t)a.items_cap * P, "baseband heat band");
+  if (a.dchr) in_ws(a.dchr, (size_t)a.items * P, "baseband heat band");
   if (a.ddump) in_ws(a.ddump, 4 * (size_t)a.items_cap * P, "baseband D dump");
   if (a.fdump) in_ws(a.fdump, 8 * (size_t)a.items_cap * P, "baseband |T'|,|R'| planes");
 }
@@ -230,7 +231,9 @@ static void check_fuse_rule(std::mt19937& rng) {
       {3840, 2160, 16, 9, 1, 0, 0, 0, 0, 2},
       {2566, 1444, 40, 9, 1, 0, 0, 0, 0, 1},   // W % 4 == 2; level 1 is 1283 columns wide (odd)
       {3841, 2160, 64, 9, 1, 0, 0, 0, 0, 0},   // odd width
-      {3840, 2160, 64, 9, 1, 2, 0, 0, 0, 0},   // heat map, features, per-pixel dump: k_band4's instantiations
+      {3840, 2160, 64, 9, 1, 2, 0, 0, 0, 3},   // heat map: the HEAT instantiations of the fused kernels (k_band4s_heat / k_band4f_heat)
+      {7680, 4320, 256, 10, 1, 3, 0, 0, 0, 4}, // configs[4]
+      // features, per-pixel dump: k_band4's instantiations
       {3840, 2160, 64, 9, 1, 0, 38, 0, 0, 0},
       {3840, 2160, 64, 9, 1, 0, 0, 1, 0, 0},
       {3840, 2160, 1, 9, 0, 0, 0, 0, 0, 0},    // an image
@@ -291,6 +294,8 @@ int main(int argc, char** argv) {
       c.raw_halo = ri(0, 1);
       c.feature_size = (c.heatmap == 0 && ri(0, 3) == 0) ? ri(1, 90) : 0;
       c.fuse_mode = ri(0, 5) == 0 ? ri(0, 3) : 0;                                        // 3: out of range, must be refused
+      c.band_layout = ri(0, 7) == 0 ? ri(0, 2) : 0;                                      // 2: out of range
+      if (c.is_video && ri(0, 3) == 0) { c.defer_bands = 1; c.score_frames = ri(0, c.block_frames + 1); }   // 0 and block + 1: out of range
       for (int i = 0; i < 4 * CVVDP_MAX_FILTER_LEN; ++i) c.taps[i] = 0.01f * (i % 7);
       for (auto& v : c.csf_rows) v = 1.0f;
       snprintf(g_case, sizeof g_case, "#%d %dx%d B%d C%d video %d fl %d frames %d/%d block %d levels %d heat %d dump %d halo %d fs %d eotf %d", k, c.width,
@@ -326,6 +331,21 @@ int main(int argc, char** argv) {
           } else {
             rc = cvvdp_process_block(h, fake_src, fake_src, ri(0, 4), st, st, 0, hs.data(), n, done, nullptr);
           }
+          if (rc == CVVDP_OK && c.defer_bands) {
+            // the block is filtered: bands and heat maps piece by piece, then what must be refused
+            for (int p0 = 0; p0 < n && rc == CVVDP_OK; p0 += c.score_frames) {
+              const int m = std::min(c.score_frames, n - p0);
+              rc = cvvdp_score_frames(h, p0, m, nullptr);
+              if (rc == CVVDP_OK && c.heatmap) rc = ri(0, 1) ? cvvdp_get_heatmap(h, m, fake_out, nullptr) : cvvdp_get_heatmap_rgb8(h, m, fake_out, nullptr);
+            }
+            if (rc == CVVDP_OK) {
+              REQUIRE(cvvdp_score_frames(h, n, 1, nullptr) != CVVDP_OK, "a piece beyond the filtered block was accepted");
+              REQUIRE(cvvdp_score_frames(h, 0, c.score_frames + 1, nullptr) != CVVDP_OK, "a piece longer than score_frames was accepted");
+            }
+            done += n;
+            continue;
+          }
+          if (rc == CVVDP_OK) REQUIRE(cvvdp_score_frames(h, 0, 1, nullptr) != CVVDP_OK, "cvvdp_score_frames on a clip without defer_bands");
           if (rc == CVVDP_OK && c.heatmap) rc = ri(0, 1) ? cvvdp_get_heatmap(h, n, fake_out, nullptr) : cvvdp_get_heatmap_rgb8(h, n, fake_out, nullptr);
           if (rc == CVVDP_OK && c.feature_size > 0) for (int b = 0; b < c.n_levels && rc == CVVDP_OK; ++b) rc = cvvdp_get_features(h, b, n, static_cast<float*>(fake_out), nullptr);
           done += n;

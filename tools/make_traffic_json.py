@@ -16,9 +16,10 @@ PIX = 3840 * 2160 * 64
 KERNELS = {
     # key: (substrings of the kernel names whose largest launches are ADDED, algorithmic bytes per step, what they are)
     "temporal_fir": (["k_fir_rot<3, 17>"], PIX * (24 + 32.0), "24 B/pixel in (fp32 RGB, test + reference) + 32 B/pixel out (8 level-0 planes)"),
-    "band_level0": (["k_band4f<4, 0>", "k_band4f<4, 1>"], PIX * 40.0,
-                    "k_band4f: g0 (32 B/pixel) in, g1 (8 B/pixel) out; two launches (strips inside the image / strips at its left and right border)"),
-    "band_level1": (["k_band4f<4, 0>#2", "k_band4f<4, 1>#2"], PIX * 10.0, "k_band4f at level 1: g1 in, g2 out"),
+    "band_level0": (["k_band4s(", "k_band4f<4, 1>"], PIX * 40.0,
+                    "k_band4s + k_band4f<4, 1>: g0 (32 B/pixel) in, g1 (8 B/pixel) out; two launches (strips inside the image on front / back waves, "
+                    "strips at its left and right border one wave per channel)"),
+    "band_level1": (["k_band4s(#2", "k_band4f<4, 1>#2"], PIX * 10.0, "the same pair at level 1: g1 in, g2 out"),
 }
 
 
@@ -73,6 +74,7 @@ def sq_of(tag, spec):
     out = {"workgroups": sizes[n], "shader_clocks_per_launch": round(clocks), "note": "counter passes run the kernels one at a time"}
     if "SQ_ACTIVE_INST_VALU" in c:
         out["valu_busy"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * clocks), 3)      # 1024 SIMDs; the counter is in quad-cycles
+        out["valu_quad_cycles"] = round(c["SQ_ACTIVE_INST_VALU"])
     if "SQ_INSTS_VALU" in c:
         out["valu_instructions_per_launch"] = round(c["SQ_INSTS_VALU"])
     if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
@@ -134,6 +136,7 @@ def main(tag):
         sq = sq_of(tag, specs[0])
         if sq:
             kernels[key]["sq"] = sq
+            kernels[key]["sq_all"] = [s for s in (sq_of(tag, sp) for sp in specs) if s]        # every launch of the group
     # what the counters were measured on: written next to them ON THE GPU BOX by tools/refresh_profiles.sh (bench.code_stamp():
     # SHA-256 of the kernel sources + header, and of the library binary).  bench.py quotes the counters only for the same sources.
     stamp = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_stamp.json")))
@@ -152,4 +155,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r03")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r04")

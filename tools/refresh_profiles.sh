@@ -4,7 +4,7 @@
 # Writes everything under gpurun_out/refresh/ (merged back by gpurun); copy the *.txt/*.json into profiles/ and run
 # tools/make_traffic_json.py <tag>.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$(pwd)
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
@@ -31,10 +31,11 @@ timeout 900 python bench.py --workload 4k256 --cpu-frames 0 --steps 2 --warmup 1
 timeout 900 python bench.py --workload 4k256 --dtype u8 --cpu-frames 0 --steps 2 --warmup 1 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --workload 4k1024 --cpu-frames 0 --steps 2 --warmup 1 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --workload 8k256pq --cpu-frames 0 --steps 2 --warmup 1 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
+timeout 900 python bench.py --workload 8k256pq --heatmap-sink device --cpu-frames 0 --steps 2 --warmup 1 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --dtype u8 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --dtype yuv420p8 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --dtype yuv420p10 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
-# 120 fps: 31-tap temporal filters (k_fir_fused, 30 halo frames); kernel_roofline.temporal_fir of this line is its roofline figure
+# 120 fps: 31-tap temporal filters (k_fir_rot<., 31>, 30 halo frames); kernel_roofline.temporal_fir of this line is its roofline figure
 timeout 900 python bench.py --fps 120 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 timeout 900 python bench.py --fps 120 --dtype u8 --cpu-frames 0 >> $OUT/${TAG}_bench_other_workloads.jsonl 2>> $OUT/bench.err
 # 3b. the multi-rank path on this one GPU: 2 ranks over gloo sharing the device (shard plan, halo frames, gather, rank-0 line),

@@ -69,13 +69,14 @@ __device__ __forceinline__ void f_lds_write4(float* p, const float (&v)[4]) {
 struct __attribute__((packed, aligned(4))) f_u4 { float x, y, z, w; };     // (rows of W % 4 == 2 frames are 8-byte aligned)
 struct __attribute__((packed, aligned(4))) f_u2 { float x, y; };
 
-template <int NCH, int EDGE, bool HEAT>
+// FEAT (band4.hip, FEATURES): the feature-pooling statistics of the ML heads -- 24 more registers, the same treatment.
+template <int NCH, int EDGE, bool HEAT, bool FEAT>
 __device__ __forceinline__ void band4f_body(const BandArgs& a) {
   constexpr bool RAG = EDGE == 2;
 #ifdef CVVDP_SAFE_LOADS
   constexpr bool F_SAFE = true;       // `make safe`: every instantiation (tests/test_safe_loads.py)
 #else
-  constexpr bool F_SAFE = HEAT;
+  constexpr bool F_SAFE = HEAT || FEAT;
 #endif
   constexpr int NP = 2 * NCH;
   __shared__ __attribute__((aligned(16))) float2 s_ve[2][NP][F_VE / 2];
@@ -317,6 +318,35 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
   for (int k = 0; k < F_BW; ++k) wr[k] = a.blur[(k + 2 * F_BW - 1 - n0) % F_BW];
   float acc = 0.0f;
 
+  // ---- FEATURES (band4.hip): two independent trackers -- |T'|, |R'| belong to row r of the contrast stage, D to the pooled row
+  float f_t[4] = {0, 0, 0, 0}, f_t2[4] = {0, 0, 0, 0}, f_r[4] = {0, 0, 0, 0}, f_r2[4] = {0, 0, 0, 0}, f_d[4] = {0, 0, 0, 0}, f_d2[4] = {0, 0, 0, 0};
+  int f_left_tr = 0, f_left_d = 0;                  // rows to the next cell-row boundary (scalar)
+  if constexpr (FEAT) { f_left_tr = f_left_d = a.fs - ys % a.fs; }
+  auto feat_store = [&](int y_last, int q0, const float (&s0)[4], const float (&s1)[4]) {   // column sums of the piece that ends with row y_last
+    if constexpr (FEAT) {
+      if (interior) {
+        const int piece = y_last / a.fs + seg;
+        const int n_valid = part ? 2 : 4;
+        float* dst = a.fsum + ((((int64_t)item * NCH + c) * a.f_pieces + piece) * 6 + q0) * W + fc0;
+        if (n_valid == 4) {
+          *reinterpret_cast<f_u4*>(dst) = f_u4{s0[0], s0[1], s0[2], s0[3]};
+          *reinterpret_cast<f_u4*>(dst + W) = f_u4{s1[0], s1[1], s1[2], s1[3]};
+        } else {
+          for (int i = 0; i < n_valid; ++i) { dst[i] = s0[i]; dst[W + i] = s1[i]; }
+        }
+      }
+    }
+  };
+  auto feat_d_row = [&](int yprev) {                // D sums: a cell row ends with row yprev (the segment's last row is the epilogue's)
+    if constexpr (FEAT) {
+      if (yprev >= ys && --f_left_d == 0) {
+        feat_store(yprev, 4, f_d, f_d2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f_d[i] = f_d2[i] = 0.0f;
+        f_left_d = a.fs;
+      }
+    }
+  };
   // pooling stage of centre row y (band4.hip stage3c)
   auto stage3c = [&](int k7) {
     const ff4 q0 = f_lds_read4(&s_q[0][4 * j]), q1 = f_lds_read4(&s_q[1][4 * j]), q2 = f_lds_read4(&s_q[2][4 * j]);
@@ -335,6 +365,11 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
       if constexpr (HEAT) {   // this channel's term of the per-pixel channel norm (cvvdp_metric.py:728-734; band4.hip stage3c)
         s_h[c][4 * j + 2 * h] = fast_pow((X.x * r0) * a.hw[c] + kEps, a.beta_tch) - a.eps_btch;
         s_h[c][4 * j + 2 * h + 1] = fast_pow((X.y * r1) * a.hw[c] + kEps, a.beta_tch) - a.eps_btch;
+      }
+      if constexpr (FEAT) {
+        const float D0 = X.x * r0, D1 = X.y * r1;
+        f_d[2 * h] += D0; f_d2[2 * h] = __builtin_fmaf(D0, D0, f_d2[2 * h]);
+        f_d[2 * h + 1] += D1; f_d2[2 * h + 1] = __builtin_fmaf(D1, D1, f_d2[2 * h + 1]);
       }
     }
     if constexpr (RAG) {
@@ -441,6 +476,8 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
     // ================= phase 1
     const int yprev = r - 1 - F_R;
     if (interior && yprev >= ys) stage3c(k7);
+    feat_d_row(yprev);
+    const bool feat_row = FEAT && r >= ys && r < ye;  // (scalar) row r belongs to this segment: its |T'|, |R'| are counted
     if (in_img) {
       float exT[4], exR[4];
       expand4(s_ve[ODD][2 * c], exT);
@@ -454,7 +491,13 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
         const float S = Sv.v[i];
         const float ct = fminf((gt[i] - exT[i]) * rLt.v[i], 1000.0f);            // lpyr_dec.py:402 (band gain :66 is in S)
         const float cr = fminf((gr[i] - exR[i]) * rLr.v[i], 1000.0f);
-        m[i] = fminf(fabsf(ct), fabsf(cr)) * S;                                  // min(|T'|,|R'|), T' = ct*S (cvvdp_metric.py:845)
+        if constexpr (FEAT) {
+          const float at = fabsf(ct) * S, ar = fabsf(cr) * S;                    // |T'|, |R'| (the channel gain inside S is divided out by k_feature_finish)
+          m[i] = fminf(at, ar);                                                  // = min(|ct|,|cr|)*S bit for bit (rounding is monotone)
+          if (feat_row) { f_t[i] += at; f_t2[i] = __builtin_fmaf(at, at, f_t2[i]); f_r[i] += ar; f_r2[i] = __builtin_fmaf(ar, ar, f_r2[i]); }
+        } else {
+          m[i] = fminf(fabsf(ct), fabsf(cr)) * S;                                // min(|T'|,|R'|), T' = ct*S (cvvdp_metric.py:845)
+        }
         d[i] = fabsf(ct - cr) * S + kEps;                                        // |T'-R'| + eps (:855, safe_pow)
       }
       f_lds_write4(&s_m[c][4 * j], m);
@@ -477,6 +520,15 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
             }
           }
         }
+      }
+    }
+    if constexpr (FEAT) {
+      if (feat_row && (--f_left_tr == 0 || r == ye - 1)) {
+        feat_store(r, 0, f_t, f_t2);
+        feat_store(r, 2, f_r, f_r2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f_t[i] = f_t2[i] = f_r[i] = f_r2[i] = 0.0f;
+        f_left_tr = a.fs;
       }
     }
     // level-l row r+5 into the reduce; an even row completes a coarse row, which rolls the window for row r+1 (even) below
@@ -548,6 +600,7 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
   auto tail_step = [&](int r) {
     const int yprev = r - 1 - F_R;
     if (interior && yprev >= ys) stage3c(k7);
+    feat_d_row(yprev);
     __syncthreads();
     heat_row(yprev);
     const int yc = r - F_R;
@@ -605,6 +658,9 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
   for (r = rreal; r < rend; ++r) tail_step(r);
   // ---- epilogue: pooling stage of the last centre row
   if (interior && (ye - 1) >= ys) stage3c(k7);
+  if constexpr (FEAT) {
+    if ((ye - 1) >= ys) feat_store(ye - 1, 4, f_d, f_d2);
+  }
   if constexpr (HEAT) {
     __syncthreads();
     heat_row(ye - 1);
@@ -626,9 +682,11 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
 #undef F_ROWPTR
 
 template <int NCH, int EDGE>
-__global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) { band4f_body<NCH, EDGE, false>(a); }
+__global__ __launch_bounds__(64 * NCH, 2) void k_band4f(BandArgs a) { band4f_body<NCH, EDGE, false, false>(a); }
 template <int NCH, int EDGE>
-__global__ __launch_bounds__(64 * NCH, 2) void k_band4f_heat(BandArgs a) { band4f_body<NCH, EDGE, true>(a); }
+__global__ __launch_bounds__(64 * NCH, 2) void k_band4f_heat(BandArgs a) { band4f_body<NCH, EDGE, true, false>(a); }
+template <int NCH, int EDGE>
+__global__ __launch_bounds__(64 * NCH, 2) void k_band4f_feat(BandArgs a) { band4f_body<NCH, EDGE, false, true>(a); }
 
 bool band4f_supported(int H, int W) { return (W & 1) == 0 && W >= 32 && H >= 32; }
 
@@ -644,8 +702,11 @@ void launch_band4f(const BandArgs& a0, hipStream_t s, hipStream_t s_edge) {
   const int n_edge = std::min(a.n_strip, 1 + band4f_right_edge_strips(a.W, a.n_strip));   // strip 0 + the right-edge strips
   a.strip0 = 0; a.n_strip_l = n_edge;
   a.per_xcd = (a.n_strip_l * a.n_seg * a.items + 7) / 8;
-  const bool heat = a.dchr != nullptr;
-  if (heat) {
+  const bool heat = a.dchr != nullptr, feat = a.fsum != nullptr;
+  if (feat) {
+    if ((a.W & 3) == 0) hipLaunchKernelGGL((k_band4f_feat<4, 1>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);
+    else hipLaunchKernelGGL((k_band4f_feat<4, 2>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);
+  } else if (heat) {
     if ((a.W & 3) == 0) hipLaunchKernelGGL((k_band4f_heat<4, 1>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);
     else hipLaunchKernelGGL((k_band4f_heat<4, 2>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);
   } else {
@@ -655,7 +716,8 @@ void launch_band4f(const BandArgs& a0, hipStream_t s, hipStream_t s_edge) {
   if (n_edge < a.n_strip) {
     a.strip0 = 1; a.n_strip_l = a.n_strip - n_edge;
     a.per_xcd = (a.n_strip_l * a.n_seg * a.items + 7) / 8;
-    if (a.one_wave_layout && heat) hipLaunchKernelGGL((k_band4f_heat<4, 0>), dim3(8 * a.per_xcd), dim3(256), 0, s, a);
+    if (a.one_wave_layout && feat) hipLaunchKernelGGL((k_band4f_feat<4, 0>), dim3(8 * a.per_xcd), dim3(256), 0, s, a);
+    else if (a.one_wave_layout && heat) hipLaunchKernelGGL((k_band4f_heat<4, 0>), dim3(8 * a.per_xcd), dim3(256), 0, s, a);
     else if (a.one_wave_layout) hipLaunchKernelGGL((k_band4f<4, 0>), dim3(8 * a.per_xcd), dim3(256), 0, s, a);
     else launch_band4s(a, s);
   }

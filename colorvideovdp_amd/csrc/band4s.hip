@@ -65,10 +65,18 @@ __device__ __forceinline__ void s_for_seq(F&& f, std::integer_sequence<int, Us..
 
 // HEAT: the level's heat-map band as well (band4.hip, HEAT): the back waves publish their channel's term of the pooled row, and one
 // barrier later the 256 back threads take one column each (lp_norm over the channels).
-template <bool HEAT>
+// FEAT: the statistics of the ML heads' feature pooling as well (band4.hip, FEATURES): per lane and column, the sums of |T'|, |T'|^2, |R'|,
+// |R'|^2 (contrast stage) and D, D^2 (pooling stage, seven rows behind) over the rows of the current cell row, stored as one row of
+// column sums per cell-row piece; k_feature_finish adds the pieces.  24 more registers in the back waves.
+struct __attribute__((packed, aligned(4))) s_u4 { float x, y, z, w; };     // 16 bytes at 4-byte alignment (rows of W % 4 == 2 frames)
+
+template <bool HEAT, bool FEAT>
 __device__ __forceinline__ void band4s_body(const BandArgs& a) {
   constexpr int NCH = 4, NP = 8;
   __shared__ __attribute__((aligned(16))) float s_h[HEAT ? NCH : 1][HEAT ? 256 : 4];   // heat-map terms of the pooled row, per channel
+  // FEAT: the column sums of D and D^2 live in LDS (lane-private: no barrier) -- with all 24 sums in registers the back waves spilled
+  // eight constants and reloaded three of them per row from scratch (level 0 of 4K x 64: 10.5 ms against 7.2 of the plain kernel)
+  __shared__ __attribute__((aligned(16))) float s_fd[2][FEAT ? NCH : 1][FEAT ? 256 : 4];
   __shared__ __attribute__((aligned(16))) float2 s_ve[2][NP][S_VE / 2];
   __shared__ __attribute__((aligned(16))) float s_g[2][NP][256];             // raw level-l row handed from the front to the back (by row parity)
   __shared__ __attribute__((aligned(16))) float s_lum[2][256];               // 1/L_T, 1/L_R
@@ -401,6 +409,36 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
     const float m1c = a.m1[c];
     const float inv_dmax = a.inv_dmax;
     const float hw_c = a.hw[c], beta_tch = a.beta_tch, eps_btch = a.eps_btch, inv_beta_tch = 1.0f / a.beta_tch, eps_inv_btch = a.eps_inv_btch;
+    // ---- FEATURES (band4.hip): two independent trackers -- |T'|, |R'| belong to row r of the contrast stage, D to the pooled row
+    float f_t[4] = {0, 0, 0, 0}, f_t2[4] = {0, 0, 0, 0}, f_r[4] = {0, 0, 0, 0}, f_r2[4] = {0, 0, 0, 0};
+    const float zero4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int f_left_tr = 0, f_left_d = 0;                  // rows to the next cell-row boundary (scalar)
+    if constexpr (FEAT) {
+      f_left_tr = f_left_d = a.fs - ys % a.fs;
+      s_lds_write4(&s_fd[0][c][4 * j], zero4);
+      s_lds_write4(&s_fd[1][c][4 * j], zero4);
+    }
+    auto feat_store = [&](int y_last, int q0, const float (&s0)[4], const float (&s1)[4]) {   // column sums of the piece that ends with row y_last
+      if constexpr (FEAT) {
+        if (interior) {
+          const int piece = y_last / a.fs + seg;
+          float* dst = a.fsum + ((((int64_t)item * NCH + c) * a.f_pieces + piece) * 6 + q0) * W + (x0 - S_HALO + 4 * j);
+          *reinterpret_cast<s_u4*>(dst) = s_u4{s0[0], s0[1], s0[2], s0[3]};
+          *reinterpret_cast<s_u4*>(dst + W) = s_u4{s1[0], s1[1], s1[2], s1[3]};
+        }
+      }
+    };
+    auto feat_d_row = [&](int yprev) {                // D sums: a cell row ends with row yprev (the segment's last row is the epilogue's)
+      if constexpr (FEAT) {
+        if (yprev >= ys && --f_left_d == 0) {
+          const sf4 fd = s_lds_read4(&s_fd[0][c][4 * j]), fd2 = s_lds_read4(&s_fd[1][c][4 * j]);
+          feat_store(yprev, 4, fd.v, fd2.v);
+          s_lds_write4(&s_fd[0][c][4 * j], zero4);
+          s_lds_write4(&s_fd[1][c][4 * j], zero4);
+          f_left_d = a.fs;
+        }
+      }
+    };
 
     // horizontal half of the expand for this lane's 4 columns from 4 coarse values (lpyr_dec.py:234-237)
     auto expand4 = [&](const float2* row, float (&ex)[4]) {
@@ -444,7 +482,14 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
         const v2f T = X * inv_dmax + M1;
         const float r0 = fast_rcp(T.x), r1 = fast_rcp(T.y);
         De[2 * h] = __builtin_fmaf(X.x, r0, kEps); De[2 * h + 1] = __builtin_fmaf(X.y, r1, kEps);
-        if constexpr (HEAT) { Dh[2 * h] = X.x * r0; Dh[2 * h + 1] = X.y * r1; }
+        if constexpr (HEAT || FEAT) { Dh[2 * h] = X.x * r0; Dh[2 * h + 1] = X.y * r1; }
+      }
+      if constexpr (FEAT) {
+        sf4 fd = s_lds_read4(&s_fd[0][c][4 * j]), fd2 = s_lds_read4(&s_fd[1][c][4 * j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fd.v[i] += Dh[i]; fd2.v[i] = __builtin_fmaf(Dh[i], Dh[i], fd2.v[i]); }
+        s_lds_write4(&s_fd[0][c][4 * j], fd.v);
+        s_lds_write4(&s_fd[1][c][4 * j], fd2.v);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc = __builtin_fmaf(De[i], De[i], acc);   // sum of (D + eps)^2; k_finalize takes the eps^2 off
@@ -498,6 +543,8 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
       // ================= phase 1
       const int yprev = r - 1 - S_R;
       if (interior && yprev >= ys) stage3c(k7);
+      feat_d_row(yprev);
+      const bool feat_row = FEAT && r >= ys && r < ye;  // (scalar) row r belongs to this segment: its |T'|, |R'| are counted
       {
         float exT[4], exR[4];
         expand4(s_ve[ODD][2 * c], exT);
@@ -511,11 +558,26 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
           const float S = Sv.v[i];
           const float ct = fminf((gt.v[i] - exT[i]) * rLt.v[i], 1000.0f);            // lpyr_dec.py:402 (band gain :66 is in S)
           const float cr = fminf((gr.v[i] - exR[i]) * rLr.v[i], 1000.0f);
-          m[i] = fminf(fabsf(ct), fabsf(cr)) * S;                                  // min(|T'|,|R'|), T' = ct*S (cvvdp_metric.py:845)
+          if constexpr (FEAT) {
+            const float at = fabsf(ct) * S, ar = fabsf(cr) * S;                    // |T'|, |R'| (the channel gain inside S is divided out by k_feature_finish)
+            m[i] = fminf(at, ar);                                                  // = min(|ct|,|cr|)*S bit for bit (rounding is monotone)
+            if (feat_row) { f_t[i] += at; f_t2[i] = __builtin_fmaf(at, at, f_t2[i]); f_r[i] += ar; f_r2[i] = __builtin_fmaf(ar, ar, f_r2[i]); }
+          } else {
+            m[i] = fminf(fabsf(ct), fabsf(cr)) * S;                                // min(|T'|,|R'|), T' = ct*S (cvvdp_metric.py:845)
+          }
           d[i] = fabsf(ct - cr) * S + kEps;                                        // |T'-R'| + eps (:855, safe_pow)
         }
         s_lds_write4(&s_m[c][4 * j], m);
         if (interior) s_lds_write4(&s_d[k7][c][4 * j - S_HALO], d);
+      }
+      if constexpr (FEAT) {
+        if (feat_row && (--f_left_tr == 0 || r == ye - 1)) {
+          feat_store(r, 0, f_t, f_t2);
+          feat_store(r, 2, f_r, f_r2);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) f_t[i] = f_t2[i] = f_r[i] = f_r2[i] = 0.0f;
+          f_left_tr = a.fs;
+        }
       }
       // s_m[c] is this wave's own row: its LDS operations execute in order, the horizontal blur needs no block barrier
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -555,6 +617,7 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
     auto tail_step = [&](int r) {
       const int yprev = r - 1 - S_R;
       if (interior && yprev >= ys) stage3c(k7);
+      feat_d_row(yprev);
       S_SYNC();
       heat_row(yprev);
       if (interior) {
@@ -578,6 +641,12 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
     for (r = rreal; r < rend; ++r) tail_step(r);
     // ---- epilogue: pooling stage of the last centre row
     if (interior && (ye - 1) >= ys) stage3c(k7);
+    if constexpr (FEAT) {
+      if ((ye - 1) >= ys) {
+        const sf4 fd = s_lds_read4(&s_fd[0][c][4 * j]), fd2 = s_lds_read4(&s_fd[1][c][4 * j]);
+        feat_store(ye - 1, 4, fd.v, fd2.v);
+      }
+    }
     if constexpr (HEAT) {
       __syncthreads();
       heat_row(ye - 1);
@@ -593,12 +662,14 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
 #endif
 }
 
-__global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) { band4s_body<false>(a); }
-__global__ __launch_bounds__(512, 4) void k_band4s_heat(BandArgs a) { band4s_body<true>(a); }
+__global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) { band4s_body<false, false>(a); }
+__global__ __launch_bounds__(512, 4) void k_band4s_heat(BandArgs a) { band4s_body<true, false>(a); }
+__global__ __launch_bounds__(512, 4) void k_band4s_feat(BandArgs a) { band4s_body<false, true>(a); }
 
 // the strips away from the image's left / right border of a fused level (launch_band4f deals them: strip0 .. strip0 + n_strip_l - 1)
 void launch_band4s(const BandArgs& a, hipStream_t s) {
-  if (a.dchr) hipLaunchKernelGGL(k_band4s_heat, dim3(8 * a.per_xcd), dim3(512), 0, s, a);
+  if (a.fsum) hipLaunchKernelGGL(k_band4s_feat, dim3(8 * a.per_xcd), dim3(512), 0, s, a);
+  else if (a.dchr) hipLaunchKernelGGL(k_band4s_heat, dim3(8 * a.per_xcd), dim3(512), 0, s, a);
   else hipLaunchKernelGGL(k_band4s, dim3(8 * a.per_xcd), dim3(512), 0, s, a);
 }
 

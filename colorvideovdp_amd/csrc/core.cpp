@@ -479,8 +479,8 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     const int clip_frames = c.total_frames > 0 ? c.total_frames : 64;
     const int nominal = c.is_video ? std::min(64, clip_frames) : 1;
     static const int fuse_max = dev_knob("CVVDP_FUSE_LEVELS", CVVDP_MAX_LEVELS);
-    // (k_band4f / k_band4s are instantiated for 4 channels, with and without the heat-map band; not with the per-pixel dump or features)
-    const bool plain = c.is_video && !c.debug_dump && c.feature_size <= 0;
+    // (k_band4f / k_band4s are instantiated for 4 channels: plain, with the heat-map band, with the feature statistics; not with the per-pixel dump)
+    const bool plain = c.is_video && !c.debug_dump;
     const bool big = (int64_t)nominal * c.batch * h->lv[0].n_strip * h->lv[0].n_seg > 1024;
     // ... and level by level only while the level itself is large (>= 16 M pixels in the nominal block): on small levels the fused
     // kernel's longer prologue and two-block occupancy cost more than the small reduce pass they replace (sweep over the number

@@ -149,7 +149,7 @@ bool band4f_supported(int H, int W) { return (W & 1) == 0 && W >= 32 && H >= 32;
 void launch_band4f(const BandArgs& a, hipStream_t, hipStream_t) {
   chk_band(a, kBand4StripWidth, "k_band4f");
   REQUIRE(band4f_supported(a.H, a.W) && a.nch == 4 && a.seg_h % 2 == 0 && a.seg_h >= 8, "k_band4f on %dx%d, %d channels, seg_h %d", a.W, a.H, a.nch, a.seg_h);
-  REQUIRE(!a.ddump && !a.fdump && !a.fsum, "k_band4f with a dump / features buffer");       // (a heat-map band: the HEAT instantiations)
+  REQUIRE(!a.ddump && !a.fdump && !(a.dchr && a.fsum), "k_band4f with a dump / per-pixel feature buffer");       // (heat-map band / column sums: the HEAT / FEAT instantiations)
   in_ws(a.g1_out, 2 * (size_t)a.nch * a.items_cap_c * a.Hc * a.Wc, "k_band4f level l+1 planes");
   REQUIRE(a.g1_out == a.gc, "k_band4f writes another buffer than the next level's planes");
 }
@@ -233,8 +233,8 @@ static void check_fuse_rule(std::mt19937& rng) {
       {3841, 2160, 64, 9, 1, 0, 0, 0, 0, 0},   // odd width
       {3840, 2160, 64, 9, 1, 2, 0, 0, 0, 3},   // heat map: the HEAT instantiations of the fused kernels (k_band4s_heat / k_band4f_heat)
       {7680, 4320, 256, 10, 1, 3, 0, 0, 0, 4}, // configs[4]
-      // features, per-pixel dump: k_band4's instantiations
-      {3840, 2160, 64, 9, 1, 0, 38, 0, 0, 0},
+      // per-pixel dump: k_band4's instantiations
+      {3840, 2160, 64, 9, 1, 0, 38, 0, 0, 3},  // features: the FEAT instantiations
       {3840, 2160, 64, 9, 1, 0, 0, 1, 0, 0},
       {3840, 2160, 1, 9, 0, 0, 0, 0, 0, 0},    // an image
       {3840, 2160, 64, 9, 1, 0, 0, 0, 2, 0},   // test hook: never / wherever possible

@@ -827,8 +827,11 @@ def test_kernel_timings_in_stats_when_asked_for():
     assert "kernel_ms" not in s2
 
 
-@pytest.mark.parametrize("W,H,F,disp", [(683, 389, 3, "standard_fhd"), (1366, 768, 2, "standard_4k"), (250, 131, 1, "standard_fhd")])
-def test_fused_features_on_ragged_multi_strip_frames(W, H, F, disp):
+@pytest.mark.parametrize("W,H,F,disp,fuse_mode", [(683, 389, 3, "standard_fhd", 0), (1366, 768, 2, "standard_4k", 0), (250, 131, 1, "standard_fhd", 0),
+                                                    # the FEAT instantiations of the fused band kernels (k_band4s_feat on the strips away from the border,
+                                                    # k_band4f_feat on the border strips): several strips and segments, W % 4 == 2 with an odd height
+                                                    (736, 416, 3, "standard_fhd", 1), (1446, 333, 2, "standard_hdr_pq", 1), (1200, 200, 3, "standard_4k", 1)])
+def test_fused_features_on_ragged_multi_strip_frames(W, H, F, disp, fuse_mode):
     """The FEAT instantiation of k_band4 (column sums per piece of a cell row + k_feature_finish) where the small fixtures do not
     reach: widths that are not a multiple of 8 (RAGGED + FEAT), several strips (cells that straddle a strip seam), several row
     segments (cell rows cut into pieces), levels of odd size; against the oracle's feature pooling, which is pinned to the real
@@ -845,8 +848,10 @@ def test_fused_features_on_ragged_multi_strip_frames(W, H, F, disp):
     o = orc.Oracle(display_name=disp, features=True)
     _, ostats = o.predict(test8, ref8, dim_order="BCFHW", frames_per_second=fps)
     m = cv.cvvdp(display_name=disp, block_frames=2)
+    m.fuse_mode = fuse_mode
     vs = cv.video_source_array(test8, ref8, fps, dim_order="BCFHW", display_photometry=m.display_photometry)
     feats, _ = m.extract_features(vs)
+    assert (m.fused_levels >= 1) == (fuse_mode == 1)
     assert len(feats) == len(ostats["features"])
     for bb, (f, want) in enumerate(zip(feats, ostats["features"])):
         got = f.cpu().numpy()

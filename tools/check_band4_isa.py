@@ -99,16 +99,20 @@ def main(paths):
 
 def check_file(path):
     text = open(path).read().split("\n")
-    starts = [i for i, l in enumerate(text) if re.match(r"^_ZN5cvvdp\d+k_band4[fs]?(_heat)?[IE].*:\s*(;.*)?$", l)]
+    starts = [i for i, l in enumerate(text) if re.match(r"^_ZN5cvvdp\d+k_band4[fs]?(_heat|_feat)?[IE].*:\s*(;.*)?$", l)]
     total_bad = 0
     for s in starts:
         e = next(i for i in range(s, len(text)) if ".end_amdhsa_kernel" in text[i] or text[i].startswith("\t.section"))
+        if "k_band4f_heat" in text[s] or "k_band4f_feat" in text[s]:
+            # the HEAT / FEAT instantiations of k_band4f use ordinary, compiler-tracked loads (band4f.hip, F_SAFE): nothing hand-issued may
+            # be left in them; what the compiler schedules around its own loads (spill reloads included) is its business
+            body = text[s:e]
+            hand = sum(1 for i, l in enumerate(body) if i > 0 and "global_load_dword" in l and "ASMSTART" in body[i - 1])
+            assert hand == 0, f"{text[s].split(':')[0]}: {hand} hand-issued loads in a compiler-managed instantiation"
+            print(f"{text[s].split(':')[0]}: compiler-managed loads, 0 hand-issued")
+            continue
         bad, n_loads, n_loops = check_kernel(text[s].split(":")[0], text[s:e])
         print(f"{text[s].split(':')[0]}: {n_loops} loops, {n_loads} loads in streaming loops, {bad} violations")
-        if "k_band4f_heat" in text[s]:
-            # the HEAT instantiations of k_band4f use ordinary, compiler-tracked loads (band4f.hip, F_SAFE): nothing hand-issued may be left
-            assert n_loads == 0 and bad == 0, f"{text[s].split(':')[0]}: hand-issued loads in a compiler-managed instantiation"
-            continue
         assert n_loads > 0, f"{text[s].split(':')[0]}: no hand-issued loads found (checker out of date?)"
         total_bad += bad
     assert starts, f"{path}: no k_band4 / k_band4f kernels found"

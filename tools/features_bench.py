@@ -25,5 +25,10 @@ def timed(fn, n=5):
 
 t_norm, _ = timed(lambda: m.predict_video_source(clip))
 t_feat, (feats, _) = timed(lambda: m.extract_features(clip))
+m.profile(True)
+m.extract_features(clip)
+torch.cuda.synchronize()
+print("extract_features kernels (ms):", {k: round(v[0], 3) for k, v in m.profile_read().items()}, "fused levels", m.fused_levels)
+m.profile(False)
 print(f"{W}x{H} x {F} frames, cells of {int(-(-m.pix_per_deg // 1))} px: predict {t_norm * 1e3:.2f} ms, extract_features {t_feat * 1e3:.2f} ms "
       f"({t_feat / t_norm:.2f} x), {len(feats)} bands, band 0 features {tuple(feats[0].shape)}")

@@ -1002,8 +1002,8 @@ def test_split_band_kernel_matches_the_one_wave_layout(W, H, F, fps, disp):
 # ---------------------------------------------------------------------------------------------------------------------
 # Heat-map clips resident in HBM (cvvdp_clip.defer_bands, cvvdp_score_frames): a long temporal block, the band / heat-map stage in
 # pieces.  Neither length may change a bit of Q_per_ch or of the heat maps.
-@pytest.mark.parametrize("mode", ["supra-threshold", "raw"])
-def test_heatmap_clips_in_hbm_are_scored_in_pieces_of_a_long_temporal_block(mode):
+@pytest.mark.parametrize("mode,fuse_mode", [("supra-threshold", 0), ("raw", 0), ("threshold", 1)])     # fuse_mode 1: the pieces on the fused band kernels
+def test_heatmap_clips_in_hbm_are_scored_in_pieces_of_a_long_temporal_block(mode, fuse_mode):
     import colorvideovdp_amd as cv
     t, r = _fuse_clip(256, 144, 41, 5)
     t, r = torch.as_tensor(t).cuda(), torch.as_tensor(r).cuda()
@@ -1011,9 +1011,9 @@ def test_heatmap_clips_in_hbm_are_scored_in_pieces_of_a_long_temporal_block(mode
     #              block, piece -> (temporal block, piece; 0 = blocks scored whole)
     for block, piece, want in ((16, None, (16, 0)), (None, None, (41, 16)), (41, 7, (41, 7)), (23, 5, (23, 5)), (41, 41, (41, 0)), (30, 16, (30, 16))):
         m = cv.cvvdp(display_name="standard_fhd", heatmap=mode, block_frames=block)
-        m.score_frames = piece
+        m.score_frames, m.fuse_mode = piece, fuse_mode
         jod, st = m.predict(t, r, dim_order="BCFHW", frames_per_second=30)
-        assert (m.last_block_frames, m.last_score_frames) == want
+        assert (m.last_block_frames, m.last_score_frames) == want and (m.fused_levels >= 1) == (fuse_mode == 1)
         runs.append((float(jod), st["Q_per_ch"], st["heatmap"].clone()))
     for jod, q, hm in runs[1:]:
         assert jod == runs[0][0]
@@ -1028,7 +1028,7 @@ def test_heatmap_clips_in_hbm_are_scored_in_pieces_of_a_long_temporal_block(mode
         got[:, :, first:first + frames.shape[2]] = frames
 
     m = cv.cvvdp(display_name="standard_fhd", heatmap=mode, block_frames=23)
-    m.score_frames = 9
+    m.score_frames, m.fuse_mode = 9, fuse_mode
     vs = cv.video_source_array(t, r, 30, dim_order="BCFHW", display_photometry=m.display_photometry)
     _, st = m.predict_video_source(vs, heatmap_sink=sink)
     assert order == [(0, 9), (9, 9), (18, 5), (23, 9), (32, 9)]

@@ -56,6 +56,9 @@ timeout 900 python tools/heatmap_bench.py 8k 24 >> $OUT/${TAG}_heatmap_bench.txt
 ( timeout 600 python tools/features_bench.py 3840x2160; timeout 600 python tools/features_bench.py 1920x1080 ) 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_features_bench.txt
 timeout 600 python tools/shard_halo_bench.py > $OUT/${TAG}_shard_halo_bench.txt 2>&1
 timeout 600 tools/shape_bench.sh 2560x1440 1920x1080 1366x768 1360x768 854x480 848x480 > $OUT/${TAG}_shape_bench.txt 2>&1
+# 3d. the two wave layouts of the fused band kernel side by side, shader clock / socket power under the step
+timeout 300 python tools/ab_layout.py 4k64 10 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_ab_layout.txt
+timeout 120 python tools/clock_power_probe.py 4 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_clock_power_probe.txt
 # 4. GPU test log
 timeout 1800 python -m pytest tests -m gpu -q > $OUT/${TAG}_pytest_gpu.log 2>&1
 tail -3 $OUT/${TAG}_pytest_gpu.log; cat $OUT/${TAG}_bench.json

@@ -54,3 +54,31 @@ def test_fused_kernel_streams_are_safe_too(tmp_path):
         bad, n_loads, n_loops = chk.check_kernel(text[s].split(":")[0], text[s:e])
         assert n_loads == 48 and bad == 0, (n_loads, bad)          # eight steps x (four neighbour loads + two row loads)
         assert "\n".join(text[s:e]).count("s_waitcnt vmcnt(2)") >= 8
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
+def test_front_back_wave_kernels_are_safe_and_fit_four_waves_per_simd(tmp_path):
+    """k_band4s / k_band4s_heat / k_band4s_feat (band4s.hip): the front waves' 8-row ring with six loads per step and ONE wait per step
+    (vmcnt(8)); 128 VGPRs at most, or the two 8-wave blocks per CU (four waves per SIMD) the layout exists for do not fit; the
+    k_band4f_heat / _feat instantiations must hold no hand-issued load at all (compiler-managed: they spill)."""
+    import re
+    spec = importlib.util.spec_from_file_location("check_band4_isa", os.path.join(ROOT, "tools", "check_band4_isa.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    asm = tmp_path / "band4s.s"
+    cmd = [HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-x", "hip",
+           "--cuda-device-only", "-S", os.path.join(ROOT, "colorvideovdp_amd", "csrc", "band4s.hip"), "-o", str(asm)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    raw = asm.read_text()
+    text = raw.split("\n")
+    starts = [i for i, l in enumerate(text) if re.match(r"^_ZN5cvvdp\d+k_band4s(_heat|_feat)?E.*:\s*(;.*)?$", l)]
+    assert len(starts) == 3
+    for s in starts:
+        e = next(i for i in range(s, len(text)) if ".end_amdhsa_kernel" in text[i] or text[i].startswith("\t.section"))
+        bad, n_loads, n_loops = chk.check_kernel(text[s].split(":")[0], text[s:e])
+        assert n_loads == 48 and bad == 0, (text[s], n_loads, bad)            # eight steps x (four neighbour loads + two row loads)
+        assert "\n".join(text[s:e]).count("s_waitcnt vmcnt(8)") >= 8
+    vg = [int(v) for v in re.findall(r"\.vgpr_count:\s+(\d+)", raw)]
+    assert len(vg) == 3 and max(vg) <= 128, vg
+    assert chk.check_file(str(asm)) == 0

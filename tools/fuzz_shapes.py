@@ -1,7 +1,8 @@
 """Randomised shape sweep of the HIP path against the CPU oracle (development aid, run on the GPU box):
-    python tools/fuzz_shapes.py [n_cases] [seed]
+    python tools/fuzz_shapes.py [n_cases] [seed] [fuse_heat]
 Random widths / heights (16..700 x 16..400, all residues mod 16), frame counts, frame rates, displays, padding and heat-map modes;
-every second video case without a heat map forces the fused band kernels (test hook fuse_mode = 1) wherever a level supports them."""
+every second video case without a heat map forces the fused band kernels (test hook fuse_mode = 1) wherever a level supports them;
+with a third argument the heat-map video cases run on the fused kernels too (k_band4s_heat / k_band4f_heat)."""
 import sys
 import numpy as np
 import torch
@@ -19,6 +20,8 @@ for cs in fuzz_cases.cases(seed, n):
     oj, os_ = o.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
     m = cv.cvvdp(display_name=disp, temp_padding=pad, heatmap=heat, block_frames=cs["block_frames"])
     fm = cs["fuse_mode"]
+    if len(sys.argv) > 3 and heat and F > 1:
+        fm = 1
     m.fuse_mode = fm
     j, s = m.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
     dq = np.abs(s["Q_per_ch"] - os_["Q_per_ch"]) / (np.abs(os_["Q_per_ch"]) * 2e-4 + 2e-6)

@@ -92,6 +92,8 @@ int check_launch(cvvdp_handle* h, const char* what) {
   return CVVDP_OK;
 }
 
+// heat maps: do the finishing kernels add the expanded level-1 reconstruction themselves (4 pixels per thread, heatmap.hip heat_recon4)?
+bool heat_l0_fused(const cvvdp_handle* h) { return h->L >= 2 && h->lv[0].W % 4 == 0 && h->lv[1].W >= 2; }
 float* gbase(const cvvdp_handle* h, int level, int set) { return h->ws + h->lv[level].g_off + (size_t)set * h->pyr_set_floats; }
 int level_cap(const cvvdp_handle* h, int level) { return level == 0 ? h->items_cap : h->items_cap_s; }
 
@@ -328,7 +330,8 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
   }
   if (heat) {  // lpyr_dec_2.reconstruct, lpyr_dec.py:328-335: coarse to fine, in place
     ProfScope ps(h, CVVDP_PROF_HEATMAP, s);
-    for (int l = L - 2; l >= 0; --l) {
+    // the last step (level 1 -> level 0) is done by the heat-map kernels themselves where they can (get_heatmap_impl): 8 B/pixel less traffic
+    for (int l = L - 2; l >= (heat_l0_fused(h) ? 1 : 0); --l) {
       ExpandAddArgs e{};
       e.fine = h->ws + h->lv[l].heat_off; e.coarse = h->ws + h->lv[l + 1].heat_off;
       e.H = h->lv[l].H; e.W = h->lv[l].W; e.Hc = h->lv[l + 1].H; e.Wc = h->lv[l + 1].W; e.n_img = items;
@@ -867,6 +870,12 @@ static int get_heatmap_impl(cvvdp_handle* h, int32_t n_frames, void* dev_out_f16
   hipStream_t s = static_cast<hipStream_t>(stream);
   HeatArgs a{};
   a.recon = h->ws + h->lv[0].heat_off;
+  if (heat_l0_fused(h)) {
+    a.coarse = h->ws + h->lv[1].heat_off;
+    a.H = h->lv[0].H; a.W = h->lv[0].W; a.Hc = h->lv[1].H; a.Wc = h->lv[1].W;
+    const float K0 = 0.25f - 0.4f / 2.0f, K1 = 0.25f, K2 = 0.4f;      // lpyr_dec.py:179 (as in run_bands)
+    a.kx[0] = K0 * 2.0f; a.kx[1] = K2 * 2.0f; a.kx[2] = K1 * 2.0f;
+  }
   a.ctx = h->ws + h->lv[0].g_off + (size_t)h->last_item0 * h->lv[0].P;  // plane 0 = test Y-sustained (cvvdp_metric.py:400)
   a.P = (int)h->lv[0].P; a.items = h->last_items; a.mode = h->c.heatmap;
   a.jod_a = h->p.jod_a; a.jod_exp = h->p.jod_exp;

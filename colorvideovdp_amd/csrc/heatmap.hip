@@ -24,6 +24,44 @@ __device__ __forceinline__ uint8_t half_to_u8(__half v) {
   return (uint8_t)__half2float(__float2half_rn(p));
 }
 
+// level-0 reconstruction of 4 adjacent pixels of row y (x % 4 == 0): band + expand(level-1 reconstruction); k_expand_add4's expressions
+__device__ __forceinline__ void heat_recon4(const HeatArgs& a, int item, int y, int x, float (&q)[4]) {
+  const float* c = a.coarse + (int64_t)item * a.Hc * a.Wc;
+  const int my = y >> 1, mx = x >> 1;
+  const int y0 = max(my - 1, 0), y2 = min(my + 1, a.Hc - 1);
+  const float e0 = a.kx[0], e1 = a.kx[1], o = a.kx[2];
+  float v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cx = min(max(mx - 1 + k, 0), a.Wc - 1);
+    if (y & 1) v[k] = c[(int64_t)my * a.Wc + cx] * o + c[(int64_t)y2 * a.Wc + cx] * o;
+    else v[k] = c[(int64_t)y0 * a.Wc + cx] * e0 + c[(int64_t)my * a.Wc + cx] * e1 + c[(int64_t)y2 * a.Wc + cx] * e0;
+  }
+  float4 t = *reinterpret_cast<const float4*>(a.recon + (int64_t)item * a.P + (int64_t)y * a.W + x);
+  t.x += v[0] * e0 + v[1] * e1 + v[2] * e0;
+  t.y += v[1] * o + v[2] * o;
+  t.z += v[1] * e0 + v[2] * e1 + v[3] * e0;
+  t.w += v[2] * o + v[3] * o;
+  q[0] = t.x; q[1] = t.y; q[2] = t.z; q[3] = t.w;
+}
+
+// raw map with the last reconstruction step fused in (a.coarse != null): 4 pixels per thread
+__global__ __launch_bounds__(256) void k_heat_raw4(HeatArgs a) {
+  const int item = blockIdx.y;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= a.P) return;
+  const int y = i / a.W, x = i - y * a.W;
+  float q[4];
+  heat_recon4(a, item, y, x, q);
+  const int64_t base = (int64_t)item * a.P + i;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const __half v = __float2half(heat_value(q[k], a.jod_a, a.jod_exp));
+    if (a.out_u8) reinterpret_cast<uint8_t*>(a.out)[base + k] = half_to_u8(v);
+    else reinterpret_cast<__half*>(a.out)[base + k] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_heat_raw(HeatArgs a) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)a.items * a.P) return;
@@ -33,6 +71,10 @@ __global__ __launch_bounds__(256) void k_heat_raw(HeatArgs a) {
 }
 
 void launch_heat_raw(const HeatArgs& a, hipStream_t s) {
+  if (a.coarse) {
+    hipLaunchKernelGGL(k_heat_raw4, dim3((a.P / 4 + 255) / 256, a.items), dim3(256), 0, s, a);
+    return;
+  }
   const int64_t n = (int64_t)a.items * a.P;
   hipLaunchKernelGGL(k_heat_raw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
 }
@@ -176,10 +218,17 @@ __global__ __launch_bounds__(256) void k_heat_colour(HeatArgs a) {
   const int item = blockIdx.y;
   constexpr int N = VEC ? 4 : 1;
   const int i = (blockIdx.x * 256 + threadIdx.x) * N;
+  // the frame's tone curve (1024 nodes + bmin, bmax, flag) in LDS: every pixel reads two neighbouring nodes picked by its luminance
+  __shared__ float s_cv[1028];
+  {
+    const float* cvg = a.curve + (int64_t)item * kHeatCurveWords;
+    for (int k = threadIdx.x; k < 1027; k += 256) s_cv[k] = cvg[k];
+  }
+  __syncthreads();
   if (i >= a.P) return;
   const uint32_t* st = a.stats + (int64_t)item * kHeatStatsWords;
   HeatPixelCtx h;
-  h.cv = a.curve + (int64_t)item * kHeatCurveWords;
+  h.cv = s_cv;
   h.clampval = __uint_as_float(st[0]);
   h.bmin = h.cv[1024]; h.bmax = h.cv[1025];
   h.lin = h.cv[1026] == 0.0f;
@@ -189,9 +238,15 @@ __global__ __launch_bounds__(256) void k_heat_colour(HeatArgs a) {
   const int64_t base = (int64_t)item * a.P + i;
   float y[N], q[N];
   if constexpr (VEC) {
-    const float4 yv = *reinterpret_cast<const float4*>(a.ctx + base), qv = *reinterpret_cast<const float4*>(a.recon + base);
+    const float4 yv = *reinterpret_cast<const float4*>(a.ctx + base);
     y[0] = yv.x; y[1] = yv.y; y[2] = yv.z; y[3] = yv.w;
-    q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+    if (a.coarse) {                      // (uniform) the last reconstruction step here instead of a read-modify-write pass over level 0
+      const int row = i / a.W;
+      heat_recon4(a, item, row, i - row * a.W, q);
+    } else {
+      const float4 qv = *reinterpret_cast<const float4*>(a.recon + base);
+      q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+    }
   } else {
     y[0] = a.ctx[base]; q[0] = a.recon[base];
   }

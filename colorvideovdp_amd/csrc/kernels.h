@@ -249,7 +249,12 @@ struct ExpandAddArgs {
 void launch_expand_add(const ExpandAddArgs& a, hipStream_t s);
 
 struct HeatArgs {
-  const float* recon;     // [items][P] reconstructed difference pyramid (level-0 heat band)
+  const float* recon;     // [items][P] reconstructed difference pyramid (level-0 heat band) -- or, with `coarse` set, the level-0 BAND alone:
+                          // the last step of the reconstruction (lpyr_dec.py:328-335: + expand of the level-1 reconstruction) is then done here,
+                          // 4 pixels per thread with k_expand_add4's expressions, and the read-modify-write pass over level 0 does not exist
+  const float* coarse;    // [items][Hc*Wc] level-1 reconstruction, or null
+  int32_t H, W, Hc, Wc;   // (coarse != null: W % 4 == 0)
+  float kx[3];
   const float* ctx;       // context image: test Y-sustained level-0 plane [items][P] (cvvdp_metric.py:400)
   int32_t P, items, mode;
   float jod_a, jod_exp;

@@ -191,6 +191,7 @@ void launch_expand_add(const ExpandAddArgs& a, hipStream_t) {
 static void chk_heat(const HeatArgs& a) {
   ++g_launches;
   in_ws(a.recon, (size_t)a.items * a.P, "heat recon");
+  if (a.coarse) { REQUIRE(a.W % 4 == 0 && (size_t)a.H * a.W == (size_t)a.P && a.Hc == (a.H + 1) / 2 && a.Wc == (a.W + 1) / 2, "heat: fused reconstruction geometry"); in_ws(a.coarse, (size_t)a.items * a.Hc * a.Wc, "heat level-1 reconstruction"); }
   if (a.ctx) in_ws(a.ctx, (size_t)a.items * a.P, "heat context");
   if (a.stats) in_ws(a.stats, (size_t)a.items * kHeatStatsWords, "heat stats");
   if (a.curve) in_ws(a.curve, (size_t)a.items * kHeatCurveWords, "heat curve");

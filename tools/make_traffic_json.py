@@ -50,7 +50,7 @@ def pick(table, spec):
     return r[n] if len(r) > n else None
 
 
-def sq_of(tag, spec):
+def sq_of(tag, spec, expect_wg=None):
     """SQ counters of one launch size of one kernel (profiles/<tag>_pmc_sq_counters.txt, tools/sq_counters.sh): shader clocks, VALU pipe
     utilisation, VALU instructions -- what bounds a kernel that is not HBM-bound."""
     path = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq_counters.txt")
@@ -67,7 +67,7 @@ def sq_of(tag, spec):
             per.setdefault(int(f[idx[0] - 1]), {})[f[idx[0]]] = float(f[idx[0] + 3])
     sizes = sorted(per, reverse=True)
     n = int(nth) - 1 if nth else 0
-    if len(sizes) <= n or "SQ_BUSY_CYCLES" not in per[sizes[n]]:
+    if len(sizes) <= n or "SQ_BUSY_CYCLES" not in per[sizes[n]] or (expect_wg is not None and sizes[n] != expect_wg):
         return None
     c = per[sizes[n]]
     clocks = c["SQ_BUSY_CYCLES"] / 32
@@ -130,13 +130,13 @@ def main(tag):
         fetch_kb = sum(f[2] for f in fs)
         write_kb = sum(w[2] for w in ws if w)
         hbm = fetch_kb * 1024 * 2 + write_kb * 1024
-        kernels[key] = {"kernel": " + ".join(sp.partition("#")[0] for sp in specs), "workgroups": [f[0] for f in fs], "FETCH_SIZE_KB_per_launch": fetch_kb,
+        kernels[key] = {"kernel": " + ".join(sp.partition("#")[0].rstrip("(") for sp in specs), "workgroups": [f[0] for f in fs], "FETCH_SIZE_KB_per_launch": fetch_kb,
                         "WRITE_SIZE_KB_per_launch": write_kb, "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": algo,
                         "measured_over_algorithmic": round(hbm / algo, 4), "algorithmic_bytes": what, "launches_sampled": fs[0][1]}
-        sq = sq_of(tag, specs[0])
+        sq = sq_of(tag, specs[0], fs[0][0])
         if sq:
             kernels[key]["sq"] = sq
-            kernels[key]["sq_all"] = [s for s in (sq_of(tag, sp) for sp in specs) if s]        # every launch of the group
+            kernels[key]["sq_all"] = [s for s in (sq_of(tag, sp, f[0]) for sp, f in zip(specs, fs)) if s]        # every launch of the group
     # what the counters were measured on: written next to them ON THE GPU BOX by tools/refresh_profiles.sh (bench.code_stamp():
     # SHA-256 of the kernel sources + header, and of the library binary).  bench.py quotes the counters only for the same sources.
     stamp = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_stamp.json")))

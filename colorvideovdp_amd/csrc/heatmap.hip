@@ -179,6 +179,8 @@ struct HeatPixelCtx {
   float clampval, bmin, bmax, step, inv_step, inv_lin;
   bool lin;
   const float* cv;
+  const float* cin;   // colour-map node positions and colours in LDS: a pixel picks its two nodes by its value (indexing the kernel
+  const float* cch;   // arguments per lane made every fetch a global load with 64-bit address arithmetic: 25 loads per 4 pixels)
 };
 __device__ __forceinline__ void heat_pixel(const HeatArgs& a, const HeatPixelCtx& h, float y, float q, __half (&out)[3]) {
   const float b = fast_log2(fmaxf(y, h.clampval)) * 0.6931471805599453f;
@@ -188,8 +190,10 @@ __device__ __forceinline__ void heat_pixel(const HeatArgs& a, const HeatPixelCtx
   } else {
     int hi = (int)ceilf((b - h.bmin) * h.inv_step);
     hi = min(max(hi, 0), 1023);
-    while (hi > 0 && scale_node(hi - 1, h.bmin, h.bmax, h.step) >= b) --hi;     // bucketize: smallest node >= b
-    while (hi < 1023 && scale_node(hi, h.bmin, h.bmax, h.step) < b) ++hi;
+    // bucketize: smallest node >= b.  The estimate is within one node of it (the nodes are bmin + step * i to 1e-7 of a step): one
+    // predicated step down, one up -- as two per-pixel while loops this was half of the kernel's instructions (divergent control flow)
+    hi = (hi > 0 && scale_node(max(hi - 1, 0), h.bmin, h.bmax, h.step) >= b) ? hi - 1 : hi;
+    hi = (hi < 1023 && scale_node(hi, h.bmin, h.bmax, h.step) < b) ? hi + 1 : hi;
     const int lo = max(hi - 1, 0);
     const float xl = scale_node(lo, h.bmin, h.bmax, h.step), xh = scale_node(hi, h.bmin, h.bmax, h.step);
     float fr = (b - xl) * fast_rcp(xh - xl + 0.000001f);
@@ -198,15 +202,17 @@ __device__ __forceinline__ void heat_pixel(const HeatArgs& a, const HeatPixelCtx
   }
   const float d = fminf(fmaxf(heat_value_fast(q, a), 0.0f), 1.0f);
   int hi = a.n_nodes;
-  for (int k = a.n_nodes - 1; k >= 0; --k)
-    if (a.cin[k] >= d) hi = k;
+#pragma unroll
+  for (int k = 4; k >= 0; --k)
+    if (k < a.n_nodes && a.cin[k] >= d) hi = k;   // (wave-uniform node positions: scalar operands of a compare + select)
   hi = min(hi, a.n_nodes - 1);
   const int lo = max(hi - 1, 0);
-  float fr = (d - a.cin[lo]) * fast_rcp(a.cin[hi] - a.cin[lo] + 0.000001f);
+  const float cl = h.cin[lo], chh = h.cin[hi];
+  float fr = (d - cl) * fast_rcp(chh - cl + 0.000001f);
   if (hi == lo || fr < 0.0f) fr = 0.0f;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float col = a.cch[lo * 3 + c] * (1.0f - fr) + a.cch[hi * 3 + c] * fr;
+    const float col = h.cch[lo * 3 + c] * (1.0f - fr) + h.cch[hi * 3 + c] * fr;
     const float c16 = __half2float(__float2half(col));                     // colour map is stored as fp16 first (:96-98)
     out[c] = __float2half(fminf(fmaxf(c16 * tmo, 0.0f), 1.0f));
   }
@@ -220,15 +226,19 @@ __global__ __launch_bounds__(256) void k_heat_colour(HeatArgs a) {
   const int i = (blockIdx.x * 256 + threadIdx.x) * N;
   // the frame's tone curve (1024 nodes + bmin, bmax, flag) in LDS: every pixel reads two neighbouring nodes picked by its luminance
   __shared__ float s_cv[1028];
+  __shared__ float s_cm[20];
   {
     const float* cvg = a.curve + (int64_t)item * kHeatCurveWords;
     for (int k = threadIdx.x; k < 1027; k += 256) s_cv[k] = cvg[k];
+    if (threadIdx.x < 5) s_cm[threadIdx.x] = a.cin[threadIdx.x];
+    else if (threadIdx.x < 20) s_cm[threadIdx.x] = a.cch[threadIdx.x - 5];
   }
   __syncthreads();
   if (i >= a.P) return;
   const uint32_t* st = a.stats + (int64_t)item * kHeatStatsWords;
   HeatPixelCtx h;
   h.cv = s_cv;
+  h.cin = s_cm; h.cch = s_cm + 5;
   h.clampval = __uint_as_float(st[0]);
   h.bmin = h.cv[1024]; h.bmax = h.cv[1025];
   h.lin = h.cv[1026] == 0.0f;

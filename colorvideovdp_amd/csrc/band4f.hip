@@ -423,6 +423,20 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
     if (base < 256) { mir_kind = fc0 == W - 8 ? 1 : 2; mir_base = base; }
   }
 
+  // HEAT, colour-mapped modes: the range of the context image from the rows the wave of channel 0 streams (band4s.hip range_row)
+  uint32_t r_mn = 0x7F7FFFFFu, r_mx = 0u;
+  auto range_row = [&](v4f v) {
+    if constexpr (HEAT) {
+      if (c == 0 && a.hstats) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t u = __float_as_uint(v[i]);
+          r_mn = min(r_mn, v[i] > 0.0f ? u : 0x7F7FFFFFu);
+          r_mx = max(r_mx, v[i] > 0.0f ? u : 0u);
+        }
+      }
+    }
+  };
   // ---- prologue: rows r_start-4 .. r_start+4 prime the reduce (three complete coarse rows in the window, two partial ones),
   // rows r_start .. r_start+4 stay in ring slots 0 .. 4, the rows after them are requested
   {
@@ -440,6 +454,7 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
       const v2f lT = ld2(gT, ar), lR = ld2(gR, ar);
       const float rT = ld1(gT, ar), rR = ld1(gR, ar);
       if (i >= 4) { ringT[i - 4] = vT; ringR[i - 4] = vR; }          // (the ring holds the rows as loaded)
+      range_row(vT);
       if (i & 1) {
         consume(ar, std::true_type{}, placed(vT), placed(vR), lT, rT, lR, rR, em);
       } else {
@@ -535,6 +550,7 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
     float4 emitted = cC;
     consume(r + 5, std::integral_constant<bool, !ODD>{}, placed(ringT[(U + 5) & 7]), placed(ringR[(U + 5) & 7]), nbLT[(U + 5) & 1], nbRT[(U + 5) & 1],
             nbLR[(U + 5) & 1], nbRR[(U + 5) & 1], emitted);
+    range_row(ringT[(U + 5) & 7]);
     coarse_finish(ODD ? 0 : 1, std::integral_constant<bool, !ODD>{}, ODD, emitted);   // vertical expand of row r+1
     __syncthreads();
     // ================= phase 2
@@ -664,6 +680,17 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
   if constexpr (HEAT) {
     __syncthreads();
     heat_row(ye - 1);
+    if (c == 0 && a.hstats) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        r_mn = min(r_mn, (uint32_t)__shfl_down((int)r_mn, off, 64));
+        r_mx = max(r_mx, (uint32_t)__shfl_down((int)r_mx, off, 64));
+      }
+      if (j == 0) {
+        atomicMin(&a.hstats[(int64_t)item * kHeatStatsWords + 0], r_mn);
+        atomicMax(&a.hstats[(int64_t)item * kHeatStatsWords + 1], r_mx);
+      }
+    }
   }
 
 #pragma unroll

@@ -537,6 +537,7 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
     __syncthreads();        // (front: luminance terms of row r_start)
 
     int slot = n0, k7 = 0;
+    uint32_t r_mn = 0x7F7FFFFFu, r_mx = 0u;
     // one real row r (0 <= r < H)
     auto step = [&](int r, auto odd_) {
       constexpr bool ODD = decltype(odd_)::value;
@@ -552,6 +553,19 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
         const sf4 rLt = s_lds_read4(&s_lum[0][4 * j]), rLr = s_lds_read4(&s_lum[1][4 * j]);
         const sf4 Sv = s_lds_read4(&s_S[c][4 * j]);
         const sf4 gt = s_lds_read4(&s_g[ODD][2 * c][4 * j]), gr = s_lds_read4(&s_g[ODD][2 * c + 1][4 * j]);
+        if constexpr (HEAT) {
+          // colour-mapped modes: the range of the context image (test Y-sustained = this level's plane 0, k_heat_range) from the raw rows the
+          // back wave of channel 0 is handed anyway -- every sample of the plane passes through some block's wave (the halo columns are
+          // samples of the neighbouring strips): minimum over the positive samples and maximum, as bit patterns
+          if (c == 0 && a.hstats) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t u = __float_as_uint(gt.v[i]);
+              r_mn = min(r_mn, gt.v[i] > 0.0f ? u : 0x7F7FFFFFu);
+              r_mx = max(r_mx, gt.v[i] > 0.0f ? u : 0u);
+            }
+          }
+        }
         float m[4], d[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -650,6 +664,17 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
     if constexpr (HEAT) {
       __syncthreads();
       heat_row(ye - 1);
+      if (c == 0 && a.hstats) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          r_mn = min(r_mn, (uint32_t)__shfl_down((int)r_mn, off, 64));
+          r_mx = max(r_mx, (uint32_t)__shfl_down((int)r_mx, off, 64));
+        }
+        if (j == 0) {
+          atomicMin(&a.hstats[(int64_t)item * kHeatStatsWords + 0], r_mn);
+          atomicMax(&a.hstats[(int64_t)item * kHeatStatsWords + 1], r_mx);
+        }
+      }
     }
 
 #pragma unroll

@@ -46,6 +46,7 @@ struct cvvdp_handle {
   size_t ws_floats = 0;
   float* ws = nullptr;
   int last_items = 0, last_item0 = 0;     // the items the band stage ran on last (count; offset inside level 0)
+  bool last_range_done = false;           // ... and whether its level-0 band kernel took the context image's range (heat maps)
   float eotf_tab[256];          // per-code display model of 8-bit sources (eotf_table), made once in cvvdp_create
   bool eotf_tab_ok = false;
   bool prof = false;
@@ -199,6 +200,7 @@ int run_pyramid_and_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, hip
 
 int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStream_t s, int l_begin, int l_end, bool fused, int item0) {
   const int B = h->c.batch, items = n_frames * B, L = h->L, nch = h->nch;
+  if (l_begin == 0) h->last_range_done = false;
   if (l_end < 0) l_end = L - 1;
   const float K[5] = {0.25f - 0.4f / 2.0f, 0.25f, 0.4f, 0.25f, 0.25f - 0.4f / 2.0f};  // lpyr_dec.py:179
   const bool heat = h->c.heatmap != CVVDP_HEATMAP_NONE;
@@ -282,6 +284,12 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
       (void)hipStreamWaitEvent(s_edge, h->ev_edge_fork, 0);
     }
     if (fused) {
+      // colour-mapped heat maps: level 0's kernels stream the context plane (test Y-sustained) anyway and take its range on the way
+      if (l == 0 && heat && h->c.heatmap != CVVDP_HEATMAP_RAW) {
+        a.hstats = reinterpret_cast<uint32_t*>(h->ws + h->hstats_off);
+        launch_heat_init(a.hstats, items, s);
+        h->last_range_done = true;
+      }
       a.g1_out = gbase(h, l + 1, set);
       for (int i = 0; i < 5; ++i) a.rk[i] = K[i];
       a.one_wave_layout = h->c.band_layout == 1;
@@ -881,6 +889,7 @@ static int get_heatmap_impl(cvvdp_handle* h, int32_t n_frames, void* dev_out_f16
   a.jod_a = h->p.jod_a; a.jod_exp = h->p.jod_exp;
   a.jod_lin = h->p.jod_a * powf(0.1f, h->p.jod_exp - 1.0f);
   a.stats = reinterpret_cast<uint32_t*>(h->ws + h->hstats_off);
+  a.range_done = h->last_range_done ? 1 : 0;
   a.curve = h->ws + h->hcurve_off;
   a.out = dev_out_f16; a.out_u8 = out_u8;
   ProfScope ps(h, CVVDP_PROF_HEATMAP, s);

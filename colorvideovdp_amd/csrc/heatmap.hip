@@ -85,6 +85,12 @@ __global__ void k_heat_init(HeatArgs a) {
   for (int i = threadIdx.x; i < kHeatStatsWords; i += blockDim.x) st[i] = (i == 0) ? 0x7F7FFFFFu : 0u;
 }
 
+// histogram words only (the range words were filled by the level-0 band kernel: HeatArgs::range_done)
+__global__ void k_heat_zero_hist(HeatArgs a) {
+  uint32_t* st = a.stats + (int64_t)blockIdx.x * kHeatStatsWords;
+  for (int i = 4 + threadIdx.x; i < kHeatStatsWords; i += blockDim.x) st[i] = 0u;
+}
+
 // min over positive y and max y of the context image (positive floats order like their bit patterns)
 __global__ __launch_bounds__(256) void k_heat_range(HeatArgs a) {
   const int item = blockIdx.y;
@@ -292,10 +298,20 @@ __global__ __launch_bounds__(256) void k_heat_colour(HeatArgs a) {
   }
 }
 
+void launch_heat_init(uint32_t* stats, int items, hipStream_t s) {
+  HeatArgs a{};
+  a.stats = stats; a.items = items;
+  hipLaunchKernelGGL(k_heat_init, dim3(items), dim3(256), 0, s, a);
+}
+
 void launch_heat_colour(const HeatArgs& a, hipStream_t s) {
   const int gx = min((a.P + 255) / 256, 1024);
-  hipLaunchKernelGGL(k_heat_init, dim3(a.items), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_heat_range, dim3(gx, a.items), dim3(256), 0, s, a);
+  if (!a.range_done) {      // (otherwise the level-0 band kernel took the range of the context plane while it streamed it)
+    hipLaunchKernelGGL(k_heat_init, dim3(a.items), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_heat_range, dim3(gx, a.items), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(k_heat_zero_hist, dim3(a.items), dim3(256), 0, s, a);   // (a second fetch of the same frames counts them again)
+  }
   hipLaunchKernelGGL(k_heat_hist, dim3(gx, a.items), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_heat_curve, dim3(a.items), dim3(256), 0, s, a);
   if (a.P % 4 == 0) hipLaunchKernelGGL(k_heat_colour<true>, dim3((a.P / 4 + 255) / 256, a.items), dim3(256), 0, s, a);

@@ -167,6 +167,8 @@ struct BandArgs {
   float kx[3];       // expand taps: 2*K[0], 2*K[2] (even), 2*K[1] (odd)
   float* partial;    // [items][n_strip*n_seg][4]
   float* dchr;       // heat band [items_cap][H*W] or null
+  uint32_t* hstats;  // fused level 0 of a colour-mapped heat-map clip: per item kHeatStatsWords words; the waves of channel 0 take the minimum
+                     // positive and the maximum sample of the test plane they stream anyway (the context image's range, k_heat_range), or null
   float hw[4];       // heat channel weights
   float beta_tch, eps_btch, eps_inv_btch;
   float* ddump;      // debug [4][items_cap][H*W] or null
@@ -263,11 +265,13 @@ struct HeatArgs {
   float* curve;           // per item 1024 tone-curve values + [1024]=b_min, [1025]=b_max, [1026]=flag(1: histogram curve)
   void* out;              // fp16 [ch][items][P], or (out_u8) uint8 [items][P][ch]
   int32_t out_u8;
+  int32_t range_done;     // stats[0], [1] were initialised before and filled by the level-0 band kernel (BandArgs::hstats): no k_heat_init / k_heat_range
   int32_t n_nodes;        // colour map nodes (5 threshold, 3 supra-threshold)
   float cin[5];           // node positions
   float cch[15];          // node colours / luminance, [node][rgb]  (visualize_diff_map.py:93-94)
 };
 void launch_heat_raw(const HeatArgs& a, hipStream_t s);
+void launch_heat_init(uint32_t* stats, int items, hipStream_t s);     // min / max / histogram words of `items` frames to their start values
 void launch_heat_colour(const HeatArgs& a, hipStream_t s);
 constexpr int kHeatStatsWords = 4 + 1024;
 constexpr int kHeatCurveWords = 1024 + 4;

@@ -124,6 +124,7 @@ static void chk_band(const BandArgs& a, int strip_w, const char* what) {
   in_ws(a.gc, 2 * (size_t)a.nch * a.items_cap_c * Pc, "band gc");
   in_ws(a.partial, (size_t)a.items * a.n_strip * a.n_seg * 4, "band partial sums");
   if (a.dchr) in_ws(a.dchr, (size_t)a.items * P, "band heat band");
+  if (a.hstats) in_ws(a.hstats, (size_t)a.items * kHeatStatsWords, "band heat-map range words");
   if (a.ddump) in_ws(a.ddump, 4 * (size_t)a.items_cap * P, "band D dump");
   if (a.fdump) in_ws(a.fdump, 8 * (size_t)a.items_cap * P, "band |T'|,|R'| planes");
   if (a.fsum) {
@@ -198,6 +199,7 @@ static void chk_heat(const HeatArgs& a) {
   REQUIRE(a.out != nullptr && a.n_nodes <= 5, "heat: out / nodes");
 }
 void launch_heat_raw(const HeatArgs& a, hipStream_t) { chk_heat(a); }
+void launch_heat_init(uint32_t* stats, int items, hipStream_t) { ++g_launches; in_ws(stats, (size_t)items * kHeatStatsWords, "heat stats (init)"); }
 void launch_heat_colour(const HeatArgs& a, hipStream_t) { chk_heat(a); }
 
 }  // namespace cvvdp

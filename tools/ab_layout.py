@@ -36,4 +36,4 @@ for rep in range(2):
         qs[layout] = st["Q_per_ch"]
         print(f"layout {layout} ({'front/back waves' if layout == 0 else 'one wave per channel'}): step {dt:7.3f} ms   " +
               "  ".join(f"{k} {v[0] / steps:6.3f}" for k, v in prof.items()) + f"   JOD {float(jod):.5f}  fused levels {m.fused_levels}", flush=True)
-print("Q_per_ch: bit-identical", bool(np.array_equal(qs[0], qs[1])), " max relative difference %.2e (two separately compiled kernels: the last bit)" % float(np.max(np.abs(qs[0] - qs[1]) / np.abs(qs[1]))))
+print("Q_per_ch: bit-identical", bool(np.array_equal(qs[0], qs[1])), " max relative difference %.2e (two separately compiled kernels: the last bit)" % float(np.max(np.abs(qs[0] - qs[1]) / np.maximum(np.abs(qs[1]), 1e-30))))

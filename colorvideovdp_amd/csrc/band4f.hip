@@ -319,9 +319,16 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
   float acc = 0.0f;
 
   // ---- FEATURES (band4.hip): two independent trackers -- |T'|, |R'| belong to row r of the contrast stage, D to the pooled row
-  float f_t[4] = {0, 0, 0, 0}, f_t2[4] = {0, 0, 0, 0}, f_r[4] = {0, 0, 0, 0}, f_r2[4] = {0, 0, 0, 0}, f_d[4] = {0, 0, 0, 0}, f_d2[4] = {0, 0, 0, 0};
+  // The 24 column sums of a lane live in LDS (lane-private: no barrier): in registers on top of the ring and the blur window the border
+  // instantiation spilled 175 VGPRs, and at levels 1, 2 the border strips' kernel is what the level waits for.
+  __shared__ __attribute__((aligned(16))) float s_f[FEAT ? 6 : 1][FEAT ? NCH : 1][FEAT ? 256 : 4];   // |T'|, |T'|^2, |R'|, |R'|^2, D, D^2
+  const float zero4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   int f_left_tr = 0, f_left_d = 0;                  // rows to the next cell-row boundary (scalar)
-  if constexpr (FEAT) { f_left_tr = f_left_d = a.fs - ys % a.fs; }
+  if constexpr (FEAT) {
+    f_left_tr = f_left_d = a.fs - ys % a.fs;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) f_lds_write4(&s_f[q][c][4 * j], zero4);
+  }
   auto feat_store = [&](int y_last, int q0, const float (&s0)[4], const float (&s1)[4]) {   // column sums of the piece that ends with row y_last
     if constexpr (FEAT) {
       if (interior) {
@@ -337,12 +344,18 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
       }
     }
   };
+  auto feat_flush = [&](int y_last, int q0) {       // sums q0, q0+1 of the piece that ends with row y_last -> global, and back to zero
+    if constexpr (FEAT) {
+      const ff4 s0 = f_lds_read4(&s_f[q0][c][4 * j]), s1 = f_lds_read4(&s_f[q0 + 1][c][4 * j]);
+      feat_store(y_last, q0, s0.v, s1.v);
+      f_lds_write4(&s_f[q0][c][4 * j], zero4);
+      f_lds_write4(&s_f[q0 + 1][c][4 * j], zero4);
+    }
+  };
   auto feat_d_row = [&](int yprev) {                // D sums: a cell row ends with row yprev (the segment's last row is the epilogue's)
     if constexpr (FEAT) {
       if (yprev >= ys && --f_left_d == 0) {
-        feat_store(yprev, 4, f_d, f_d2);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) f_d[i] = f_d2[i] = 0.0f;
+        feat_flush(yprev, 4);
         f_left_d = a.fs;
       }
     }
@@ -368,8 +381,12 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
       }
       if constexpr (FEAT) {
         const float D0 = X.x * r0, D1 = X.y * r1;
-        f_d[2 * h] += D0; f_d2[2 * h] = __builtin_fmaf(D0, D0, f_d2[2 * h]);
-        f_d[2 * h + 1] += D1; f_d2[2 * h + 1] = __builtin_fmaf(D1, D1, f_d2[2 * h + 1]);
+        float2* pd = reinterpret_cast<float2*>(&s_f[4][c][4 * j + 2 * h]);
+        float2* pd2 = reinterpret_cast<float2*>(&s_f[5][c][4 * j + 2 * h]);
+        float2 fd = *pd, fd2 = *pd2;
+        fd.x += D0; fd2.x = __builtin_fmaf(D0, D0, fd2.x);
+        fd.y += D1; fd2.y = __builtin_fmaf(D1, D1, fd2.y);
+        *pd = fd; *pd2 = fd2;
       }
     }
     if constexpr (RAG) {
@@ -501,6 +518,10 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
       const ff4 Sv = f_lds_read4(&s_S[c][4 * j]);
       const float gt[4] = {pT.x, pT.y, pT.z, pT.w}, gr[4] = {pR.x, pR.y, pR.z, pR.w};
       float m[4], d[4];
+      ff4 f_t = ff4{{0, 0, 0, 0}}, f_t2 = f_t, f_r = f_t, f_r2 = f_t;
+      if constexpr (FEAT) {
+        if (feat_row) { f_t = f_lds_read4(&s_f[0][c][4 * j]); f_t2 = f_lds_read4(&s_f[1][c][4 * j]); f_r = f_lds_read4(&s_f[2][c][4 * j]); f_r2 = f_lds_read4(&s_f[3][c][4 * j]); }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float S = Sv.v[i];
@@ -509,7 +530,7 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
         if constexpr (FEAT) {
           const float at = fabsf(ct) * S, ar = fabsf(cr) * S;                    // |T'|, |R'| (the channel gain inside S is divided out by k_feature_finish)
           m[i] = fminf(at, ar);                                                  // = min(|ct|,|cr|)*S bit for bit (rounding is monotone)
-          if (feat_row) { f_t[i] += at; f_t2[i] = __builtin_fmaf(at, at, f_t2[i]); f_r[i] += ar; f_r2[i] = __builtin_fmaf(ar, ar, f_r2[i]); }
+          if (feat_row) { f_t.v[i] += at; f_t2.v[i] = __builtin_fmaf(at, at, f_t2.v[i]); f_r.v[i] += ar; f_r2.v[i] = __builtin_fmaf(ar, ar, f_r2.v[i]); }
         } else {
           m[i] = fminf(fabsf(ct), fabsf(cr)) * S;                                // min(|T'|,|R'|), T' = ct*S (cvvdp_metric.py:845)
         }
@@ -517,6 +538,9 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
       }
       f_lds_write4(&s_m[c][4 * j], m);
       if (interior) f_lds_write4(&s_d[k7][c][4 * j - F_HALO], d);
+      if constexpr (FEAT) {
+        if (feat_row) { f_lds_write4(&s_f[0][c][4 * j], f_t.v); f_lds_write4(&s_f[1][c][4 * j], f_t2.v); f_lds_write4(&s_f[2][c][4 * j], f_r.v); f_lds_write4(&s_f[3][c][4 * j], f_r2.v); }
+      }
       if (mir_block) {
         if (mir_kind != 0) {
           const float v0 = mir_kind == 1 ? m[1] : m[0], v1 = mir_kind == 1 ? m[2] : m[1], v2 = mir_kind == 1 ? m[3] : m[2];
@@ -539,10 +563,8 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
     }
     if constexpr (FEAT) {
       if (feat_row && (--f_left_tr == 0 || r == ye - 1)) {
-        feat_store(r, 0, f_t, f_t2);
-        feat_store(r, 2, f_r, f_r2);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) f_t[i] = f_t2[i] = f_r[i] = f_r2[i] = 0.0f;
+        feat_flush(r, 0);
+        feat_flush(r, 2);
         f_left_tr = a.fs;
       }
     }
@@ -675,7 +697,7 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
   // ---- epilogue: pooling stage of the last centre row
   if (interior && (ye - 1) >= ys) stage3c(k7);
   if constexpr (FEAT) {
-    if ((ye - 1) >= ys) feat_store(ye - 1, 4, f_d, f_d2);
+    if ((ye - 1) >= ys) feat_flush(ye - 1, 4);
   }
   if constexpr (HEAT) {
     __syncthreads();

@@ -410,7 +410,7 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
     const float inv_dmax = a.inv_dmax;
     const float hw_c = a.hw[c], beta_tch = a.beta_tch, eps_btch = a.eps_btch, inv_beta_tch = 1.0f / a.beta_tch, eps_inv_btch = a.eps_inv_btch;
     // ---- FEATURES (band4.hip): two independent trackers -- |T'|, |R'| belong to row r of the contrast stage, D to the pooled row
-    float f_t[4] = {0, 0, 0, 0}, f_t2[4] = {0, 0, 0, 0}, f_r[4] = {0, 0, 0, 0}, f_r2[4] = {0, 0, 0, 0};
+    v2f f_t[2] = {0.0f, 0.0f}, f_t2[2] = {0.0f, 0.0f}, f_r[2] = {0.0f, 0.0f}, f_r2[2] = {0.0f, 0.0f};   // (column pairs: packed adds / FMAs)
     const float zero4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     int f_left_tr = 0, f_left_d = 0;                  // rows to the next cell-row boundary (scalar)
     if constexpr (FEAT) {
@@ -566,7 +566,7 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
             }
           }
         }
-        float m[4], d[4];
+        float m[4], d[4], at4[4], ar4[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float S = Sv.v[i];
@@ -575,7 +575,7 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
           if constexpr (FEAT) {
             const float at = fabsf(ct) * S, ar = fabsf(cr) * S;                    // |T'|, |R'| (the channel gain inside S is divided out by k_feature_finish)
             m[i] = fminf(at, ar);                                                  // = min(|ct|,|cr|)*S bit for bit (rounding is monotone)
-            if (feat_row) { f_t[i] += at; f_t2[i] = __builtin_fmaf(at, at, f_t2[i]); f_r[i] += ar; f_r2[i] = __builtin_fmaf(ar, ar, f_r2[i]); }
+            at4[i] = at; ar4[i] = ar;
           } else {
             m[i] = fminf(fabsf(ct), fabsf(cr)) * S;                                // min(|T'|,|R'|), T' = ct*S (cvvdp_metric.py:845)
           }
@@ -583,13 +583,24 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
         }
         s_lds_write4(&s_m[c][4 * j], m);
         if (interior) s_lds_write4(&s_d[k7][c][4 * j - S_HALO], d);
+        if constexpr (FEAT) {
+          if (feat_row) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const v2f at2 = {at4[2 * h], at4[2 * h + 1]}, ar2 = {ar4[2 * h], ar4[2 * h + 1]};
+              f_t[h] += at2; f_t2[h] += at2 * at2; f_r[h] += ar2; f_r2[h] += ar2 * ar2;
+            }
+          }
+        }
       }
       if constexpr (FEAT) {
         if (feat_row && (--f_left_tr == 0 || r == ye - 1)) {
-          feat_store(r, 0, f_t, f_t2);
-          feat_store(r, 2, f_r, f_r2);
+          const float t0[4] = {f_t[0].x, f_t[0].y, f_t[1].x, f_t[1].y}, t1[4] = {f_t2[0].x, f_t2[0].y, f_t2[1].x, f_t2[1].y};
+          const float r0[4] = {f_r[0].x, f_r[0].y, f_r[1].x, f_r[1].y}, r1[4] = {f_r2[0].x, f_r2[0].y, f_r2[1].x, f_r2[1].y};
+          feat_store(r, 0, t0, t1);
+          feat_store(r, 2, r0, r1);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) f_t[i] = f_t2[i] = f_r[i] = f_r2[i] = 0.0f;
+          for (int h = 0; h < 2; ++h) { f_t[h] = 0.0f; f_t2[h] = 0.0f; f_r[h] = 0.0f; f_r2[h] = 0.0f; }
           f_left_tr = a.fs;
         }
       }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ISA-derived VALU budget of k_band4<4> (the level-0 band kernel): instruction counts per stage of the steady-state row loop, read
-from the assembly of the build (colorvideovdp_amd/csrc/build/band4.s, written by `make`), priced with the per-instruction costs
+from the assembly of the build (colorvideovdp_amd/csrc/build/band4-hip-amdgcn-amd-amdhsa-gfx950.s, kept by `make`), priced with the per-instruction costs
 measured on MI355X (profiles/r01_ubench_valu_rates.txt: ns per wave64 instruction per SIMD; except v_cndmask: that file's 9.9 ns was
 the micro-benchmark's own serial VCC dependence -- taking four v_cndmask per row out of k_band4f changed its time by nothing
 (profiles/r03_dev_notes.txt 12), so a select is priced like the other one-pass integer / compare operations).
@@ -148,4 +148,4 @@ def main(path, fused=False):
 if __name__ == "__main__":
     args = [x for x in sys.argv[1:] if x != "--fused"]
     fused = "--fused" in sys.argv[1:]
-    main(args[0] if args else os.path.join(ROOT, "colorvideovdp_amd", "csrc", "build", "band4f.s" if fused else "band4.s"), fused)
+    main(args[0] if args else os.path.join(ROOT, "colorvideovdp_amd", "csrc", "build", ("band4f" if fused else "band4") + "-hip-amdgcn-amd-amdhsa-gfx950.s"), fused)

@@ -809,6 +809,51 @@ def test_8k_pq_full_temporal_window_heatmap_and_distogram_against_reference():
         np.testing.assert_allclose(panels, g[key], rtol=5e-4, atol=2e-6)
 
 
+def test_4k_heatmap_clip_in_pieces_on_the_fused_kernels_against_reference():
+    """Everything round 4 added to the heat-map path at the size where all of it is active, against the real reference
+    (oracle/make_goldens_4k_heat.py): 20 frames of the 3840x2160 clip resident in HBM, threshold heat map -- a 20-frame temporal block scored
+    in pieces of 16 + 4 frames, two levels on k_band4s_heat / k_band4f_heat, the context plane's range from the level-0 band kernels, the
+    last reconstruction step inside the finishing kernels."""
+    import bench
+    import colorvideovdp_amd as cv
+    g = load_golden("deep_4k_thr_heat_20f")
+    W, H, F = int(g["width"]), int(g["height"]), int(g["frames"])
+    clip = bench.ResidentClip(F, 0, F, H, W, float(g["fps"]), "u8", torch.device("cuda"), gen="cpu")
+    if (clip.checksum_test, clip.checksum_ref) != (int(g["checksum_test"]), int(g["checksum_ref"])):
+        pytest.fail("this torch build's CPU generator does not reproduce the fixture's synthetic frames (checksum mismatch)")
+    m = cv.cvvdp(display_name=str(g["display"]), heatmap=str(g["heatmap_mode"]))
+    jod, stats = m.predict_video_source(clip)
+    assert (m.last_block_frames, m.last_score_frames) == (20, 16) and m.fused_levels == 2     # (a 20-frame clip: level 2 holds 10 M pixels, below the fuse rule)
+    assert abs(float(jod) - float(g["jod"])) <= JOD_TOL
+    np.testing.assert_allclose(stats["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
+    hm = stats["heatmap"]
+    assert tuple(hm.shape) == (1, 3, F, H, W) and hm.dtype == torch.float16
+    keep = [int(k) for k in g["heatmap_frames"]]
+    _check_heatmap(hm[0][:, keep, ::16, ::16], g["heatmap_ds"], "deep_4k_thr_heat_20f")
+    means = np.array([float(hm[0, :, f].float().mean()) for f in range(F)], dtype=np.float32)
+    np.testing.assert_allclose(means, g["heatmap_frame_means"], atol=2e-4)
+    st = {k: v for k, v in stats.items() if k != "heatmap"}
+    for jm, key in ((None, "disto_auto"), (10, "disto_10")):
+        panels, _ = m.distogram_data(st, jod_max=jm)
+        assert panels.shape == g[key].shape
+        np.testing.assert_allclose(panels, g[key], rtol=5e-4, atol=2e-6)
+    # and the same frames through a device-resident sink, unfused, in other pieces: the same scores to rounding, the same map to fp16 codes
+    m2 = cv.cvvdp(display_name=str(g["display"]), heatmap=str(g["heatmap_mode"]), block_frames=13)
+    m2.fuse_mode, m2.score_frames = 2, 5
+    got = torch.zeros((3, F, H // 16 + (H % 16 > 0), W // 16), dtype=torch.float16)
+
+    class Sink:
+        wants_device = True
+
+        def __call__(self, first, frames):
+            got[:, first:first + frames.shape[2]] = frames[0, :, :, ::16, ::16].cpu()
+
+    jod2, st2 = m2.predict_video_source(clip, heatmap_sink=Sink())
+    assert m2.fused_levels == 0 and abs(float(jod2) - float(g["jod"])) <= JOD_TOL
+    np.testing.assert_allclose(st2["Q_per_ch"], g["Q_per_ch"], rtol=2e-4, atol=2e-6)
+    _check_heatmap(got[:, keep], g["heatmap_ds"])
+
+
 def test_kernel_timings_in_stats_when_asked_for():
     """HIP-event timings of the kernel families exposed in `stats` (opt-in: the reference's stats keys stay as they are)."""
     g = load_golden("vid_u8_72x128x12_60_fhd")

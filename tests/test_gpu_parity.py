@@ -750,6 +750,28 @@ def test_ml_head_features_against_reference():
     assert k == 2
 
 
+def test_ml_head_features_of_a_4k_clip_against_reference():
+    """The FEAT instantiations of the fused band kernels at the size they are chosen for: 16 frames of the 3840x2160 bench clip, all bands'
+    pooled statistics against the real reference's extract_features (oracle/make_goldens_features_4k.py)."""
+    import bench
+    import colorvideovdp_amd as cv
+    g = load_golden("features_4k16")
+    W, H, F = int(g["width"]), int(g["height"]), int(g["frames"])
+    clip = bench.ResidentClip(F, 0, F, H, W, float(g["fps"]), "u8", torch.device("cuda"), gen="cpu")
+    if (clip.checksum_test, clip.checksum_ref) != (int(g["checksum_test"]), int(g["checksum_ref"])):
+        pytest.fail("this torch build's CPU generator does not reproduce the fixture's synthetic frames (checksum mismatch)")
+    m = cv.cvvdp(display_name=str(g["display"]))
+    feats, hm = m.extract_features(clip)
+    assert hm is None and len(feats) == int(g["bands"]) and m.fused_levels == 2
+    for bb, f in enumerate(feats):
+        want, got = g[f"band{bb}"], f.cpu().numpy()
+        assert got.shape == want.shape, (bb, got.shape, want.shape)
+        for q in (0, 2, 4):
+            np.testing.assert_allclose(got[..., q], want[..., q], rtol=5e-4, atol=2e-6, err_msg=f"band {bb} mean {q}")
+            scale = np.abs(want[..., q]) ** 2 + np.abs(want[..., q + 1])
+            assert np.all(np.abs(got[..., q + 1] - want[..., q + 1]) <= 2e-3 * scale + 1e-7), f"band {bb} var {q + 1}"
+
+
 def test_large_ragged_frames_split_off_their_edge_strips():
     """W % 8 != 0 on a frame large enough that the aligned strips alone are two GPU-fulls of workgroups: those strips run the
     aligned instantiation of k_band4 and only the edge strip the RAGGED one, as two launches (core.cpp: split_edge, decided from the

@@ -4,6 +4,7 @@
     bench_fhd64_f32   1920x1080 x 64 frames @60, standard_fhd, fp32 input   (BASELINE.json configs[1], bench --workload fhd64)
     bench_4k64_f32    3840x2160 x 64 frames @60, standard_4k,  fp32 input   (BASELINE.json metric clip, bench --workload 4k64)
     bench_4k256_u8    3840x2160 x 256 frames @60, standard_4k, uint8 input  (configs[2]; u8 so the clip fits host memory)
+    bench_4k40_u8_120fps  3840x2160 x 40 frames @120, standard_4k, uint8 input (the 31-tap temporal filters of `bench.py --fps 120` at full size)
     bench_8k_pq_heat_2f  7680x4320 x 2 frames @60, standard_hdr_pq, supra-threshold heat map (configs[4]'s outputs;
                          the fp16 heat map is stored subsampled: every 16th pixel of both frames + its mean)
 
@@ -36,6 +37,7 @@ CASES = (
     ("bench_8k_pq_heat_2f", 7680, 4320, 2, 60, "standard_hdr_pq", "u8", "supra-threshold"),
     ("bench_4k64_f32", 3840, 2160, 64, 60, "standard_4k", "f32", None),
     ("bench_4k256_u8", 3840, 2160, 256, 60, "standard_4k", "u8", None),
+    ("bench_4k40_u8_120fps", 3840, 2160, 40, 120, "standard_4k", "u8", None),      # bench --fps 120 (31-tap filters), 40 frames: longer than the filter
 )
 
 

@@ -3,6 +3,7 @@
 
     python bench.py [--gpus N --steps K --warmup W] [--workload 4k64|fhd64|4k256|4k1024|8k256pq] [--dtype f32|u8|yuv420p8|yuv420p10]
                     [--heatmap none|raw|threshold|supra-threshold] [--distogram] [--gen cpu|gpu]
+    python bench.py --gpus N ...            # N > 1 without a launcher: starts its own ranks through torch.distributed.run (self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one full predict() of the workload clip pair (display model -> DKL -> temporal FIR ->
@@ -350,6 +351,24 @@ def lockstep_spinup(step, seconds, world, flag_device, sync=lambda: None, collec
         n += 1
 
 
+def self_launch(n):
+    """Re-run this command line under `python -m torch.distributed.run --nproc-per-node n` (the driver's N=1 command
+    shape, `python bench.py --gpus N ...`, must also produce the N>1 lines).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:       # a free loopback port
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,9 +396,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher (the command shape of the N=1 line): become the launcher.  One rank per GPU
+        # through torch.distributed.run on the loopback address, same arguments; rank 0 prints the JSON line, this process only
+        # forwards the exit code.  The GPU count is checked HERE, before any rendezvous, unless the test hook pins the ranks.
+        if "CVVDP_BENCH_DEVICE" not in os.environ and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this node shows {torch.cuda.device_count()}")
+        raise SystemExit(self_launch(args.gpus))
     # test hooks: CVVDP_BENCH_DEVICE pins every rank to one GPU and CVVDP_BENCH_BACKEND=gloo replaces RCCL, so that the
     # multi-rank path (shard plan, halo frames, all-gather, rank-0 JSON) can be exercised on a single-GPU box
     dev_index = int(os.environ.get("CVVDP_BENCH_DEVICE", local_rank))

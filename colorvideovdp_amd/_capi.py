@@ -106,7 +106,7 @@ SYMBOLS = {
 # side are benchmarked against each other): CVVDP_LIB=<path> is honoured when CVVDP_DEV_KNOBS=1 is set as well.
 _IN_TREE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcvvdp_hip.so")
 LIB_PATH = (os.environ.get("CVVDP_LIB") if os.environ.get("CVVDP_DEV_KNOBS") == "1" else None) or _IN_TREE
-BUILD_DEV_KNOBS = 1
+BUILD_DEV_KNOBS, BUILD_SAFE_LOADS, BUILD_DIAG = 1, 2, 4
 _lib = None
 
 
@@ -127,6 +127,12 @@ def lib():
         v = l.cvvdp_abi_version()
         if v != ABI_VERSION:
             raise ImportError(f"libcvvdp_hip.so has ABI {v}, binding expects {ABI_VERSION}")
+        flags = l.cvvdp_build_flags()
+        if flags != 0 and os.environ.get("CVVDP_DEV_KNOBS") != "1":
+            # environment tuning knobs, compiler-managed loads (`make safe`) or a timing-only switch of the band kernels compiled in:
+            # not the product.  Such a library is loaded only when a development library was asked for explicitly.
+            raise ImportError(f"{LIB_PATH} is not a product build (cvvdp_build_flags() = {flags}: 1 dev knobs, 2 safe loads, 4 timing-only "
+                              "diagnostics); rebuild it with `make -C colorvideovdp_amd/csrc`, or set CVVDP_DEV_KNOBS=1 to load it anyway")
         sp, sc = C.c_int32(), C.c_int32()
         l.cvvdp_struct_sizes(C.byref(sp), C.byref(sc))
         if (sp.value, sc.value) != (C.sizeof(Params), C.sizeof(Clip)):

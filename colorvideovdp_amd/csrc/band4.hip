@@ -384,9 +384,6 @@ __global__ __launch_bounds__(64 * NCH, FEAT ? 2 : 3) void k_band4(BandArgs a) {
   v4f p0T = 0.0f, p0R = 0.0f, p1T = 0.0f, p1R = 0.0f;       // g rows of the even / odd row in flight
 // (no nontemporal hint: with the XCD-aware block order the halo columns and edge lines a strip shares with its neighbours
 // are L2 hits, 11.2 instead of 12.0 MB-K of FETCH_SIZE per 4K x 64 launch)
-#ifndef B4_NT_STR
-#define B4_NT_STR ""
-#endif
 #ifdef CVVDP_SAFE_LOADS
 // `make safe`: the same kernel with ordinary loads the compiler tracks and waits for itself (tests/test_safe_loads.py)
 #define B4_G_LOAD(dst, plane, row) \
@@ -396,7 +393,7 @@ __global__ __launch_bounds__(64 * NCH, FEAT ? 2 : 3) void k_band4(BandArgs a) {
 #define B4_WAIT_ODD() do { } while (0)
 #else
 #define B4_G_LOAD(dst, plane, row) \
-  asm volatile("global_load_dwordx4 %0, %1, %2" B4_NT_STR : "+v"(dst) : "v"(goff), "s"((plane) + (int64_t)(row) * W))
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(goff), "s"((plane) + (int64_t)(row) * W))
 #define B4_C_LOAD(dst, row) \
   asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst) : "v"(gcl + (int64_t)(row) * Wc))
 #define B4_WAIT_EVEN() asm volatile("s_waitcnt vmcnt(3)" : "+v"(p0T), "+v"(p0R))
@@ -683,6 +680,14 @@ void launch_band4(const BandArgs& a0, bool split_edge, hipStream_t s, hipStream_
     a.per_xcd = (a.n_strip_l * a.n_seg * a.items + 7) / 8;
     launch_band4_w<false>(a, s);
   }
+}
+
+int tu_flags_band4() {
+#ifdef CVVDP_SAFE_LOADS
+  return CVVDP_BUILD_SAFE_LOADS;
+#else
+  return 0;
+#endif
 }
 
 }  // namespace cvvdp

@@ -772,4 +772,12 @@ void launch_band4f(const BandArgs& a0, hipStream_t s, hipStream_t s_edge) {
   }
 }
 
+int tu_flags_band4f() {
+  int f = 0;
+#ifdef CVVDP_SAFE_LOADS
+  f |= CVVDP_BUILD_SAFE_LOADS;
+#endif
+  return f;
+}
+
 }  // namespace cvvdp

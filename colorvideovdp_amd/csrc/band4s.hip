@@ -709,4 +709,16 @@ void launch_band4s(const BandArgs& a, hipStream_t s) {
   else hipLaunchKernelGGL(k_band4s, dim3(8 * a.per_xcd), dim3(512), 0, s, a);
 }
 
+int tu_flags_band4s() {
+  int f = 0;
+#ifdef CVVDP_SAFE_LOADS
+  f |= CVVDP_BUILD_SAFE_LOADS;
+#endif
+#if defined(S_DIAG_NOBAR) || defined(S_DIAG_BACK_ONLY) || defined(S_DIAG_FRONT_ONLY) || defined(S_DIAG_NO_STORE) || defined(S_DIAG_PLAIN_STORE) || \
+    defined(S_DIAG_NO_NB) || defined(S_DIAG_NO_SG) || defined(S_DIAG_NO_LUM) || defined(S_PRIO_FRONT) || defined(S_PRIO_BACK) || CVVDP_BAND4S_RING != 8
+  f |= CVVDP_BUILD_DIAG;
+#endif
+  return f;
+}
+
 }  // namespace cvvdp

@@ -272,6 +272,14 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
     // (and before the next level reads what this one wrote) -- it fills the GPU together with the other strips.  The profiling
     // events of the level sit on s before the fork and after the join: they time the pair of launches.
     hipStream_t s_edge = s;
+    // colour-mapped heat maps: level 0's fused kernels stream the context plane (test Y-sustained) anyway and take its range on the way
+    // (atomic min / max into hstats).  The words are initialised HERE, on s BEFORE the fork event: the border strips' kernel runs on the
+    // edge stream and must be ordered after the initialisation (enqueued after the fork it could wipe their contribution).
+    if (fused && l == 0 && heat && h->c.heatmap != CVVDP_HEATMAP_RAW) {
+      a.hstats = reinterpret_cast<uint32_t*>(h->ws + h->hstats_off);
+      launch_heat_init(a.hstats, items, s);
+      h->last_range_done = true;
+    }
     if (fused || (lv.vec4 && lv.split_edge)) {
       if (!h->edge_stream) {
         if (hipStreamCreateWithFlags(&h->edge_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -284,12 +292,6 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
       (void)hipStreamWaitEvent(s_edge, h->ev_edge_fork, 0);
     }
     if (fused) {
-      // colour-mapped heat maps: level 0's kernels stream the context plane (test Y-sustained) anyway and take its range on the way
-      if (l == 0 && heat && h->c.heatmap != CVVDP_HEATMAP_RAW) {
-        a.hstats = reinterpret_cast<uint32_t*>(h->ws + h->hstats_off);
-        launch_heat_init(a.hstats, items, s);
-        h->last_range_done = true;
-      }
       a.g1_out = gbase(h, l + 1, set);
       for (int i = 0; i < 5; ++i) a.rk[i] = K[i];
       a.one_wave_layout = h->c.band_layout == 1;
@@ -396,11 +398,11 @@ void cvvdp_destroy(cvvdp_handle* h) {
 
 const char* cvvdp_last_error(const cvvdp_handle* h) { return h ? t_err.c_str() : "null handle"; }
 int cvvdp_build_flags(void) {
+  int f = tu_flags_band4() | tu_flags_band4f() | tu_flags_band4s();     // each band translation unit reports how IT was compiled
 #ifdef CVVDP_DEV_KNOBS
-  return CVVDP_BUILD_DEV_KNOBS;
-#else
-  return 0;
+  f |= CVVDP_BUILD_DEV_KNOBS;
 #endif
+  return f;
 }
 
 int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {

@@ -197,6 +197,11 @@ void launch_band4f(const BandArgs& a, hipStream_t s, hipStream_t s_edge);
 // band4s.hip: the border-free strips of a fused level (a.strip0 .. a.strip0 + a.n_strip_l - 1) with the work divided between front and back waves
 void launch_band4s(const BandArgs& a, hipStream_t s);
 constexpr int kBand4StripWidth = 240;
+// How each band translation unit was compiled, for cvvdp_build_flags(): CVVDP_BUILD_SAFE_LOADS (-DCVVDP_SAFE_LOADS) and CVVDP_BUILD_DIAG
+// (a timing-only switch or a non-default ring / load-hint macro: results wrong or not the product's).  0 for the product build.
+int tu_flags_band4();
+int tu_flags_band4f();
+int tu_flags_band4s();
 
 struct BaseArgs {
   const float* g;    // baseband planes [2*nch][items_cap][P]

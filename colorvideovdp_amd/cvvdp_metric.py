@@ -23,7 +23,7 @@ import torch
 
 from . import _capi
 from . import host_setup as hs
-from .config import load_config
+from .config import config_files, json2dict, load_config
 from .display_model import vvdp_display_geometry, vvdp_display_photo_eotf, vvdp_display_photometry
 from .sharding import all_gather_frames, plan_frame_shard
 from .video_source import video_source, video_source_array
@@ -113,13 +113,28 @@ class cvvdp(vq_metric):
         except Exception:
             pass
 
+    def __getattr__(self, name):
+        # only reached when normal lookup fails: the numeric model parameters as the reference's tensor attributes (read-only view
+        # of self.parameters; to change them use update_from_checkpoint, which also re-makes the core's handle)
+        p = self.__dict__.get("parameters")
+        if p is not None and name in p and not isinstance(p[name], (str, bool)):
+            return torch.as_tensor(p[name], dtype=torch.float32 if isinstance(p[name], (float, list)) else None)
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+
     def train(self, do_training=True):
         self.training_mode = do_training
 
     # ------------------------------------------------------------------ configuration
     def load_config(self, config_paths):
         """cvvdp_metric.py:146-229.  Only the shipped model family is implemented by the kernels."""
-        p = load_config("cvvdp_parameters.json", config_paths)
+        self.parameters_file = config_files.find("cvvdp_parameters.json", config_paths)
+        self._config_paths = list(config_paths)
+        self._set_parameters(json2dict(self.parameters_file))
+
+    def _set_parameters(self, p):
+        """Second half of the reference's load_config: the parameter dictionary becomes the metric's state and the core's handle is
+        re-made from it.  `self.parameters` is what the kernels are configured from; its numeric entries can also be READ as tensor
+        attributes of the same name (`metric.mask_c`, ...: `__getattr__`), the way the reference keeps them (cvvdp_metric.py:153-219)."""
         self.parameters = p
         if p["masking_model"] != "mult-mutual" or p["contrast"] != "weber_g1" or p["dclamp_type"] != "soft" \
                 or p["csf"] != "weber_fixed_size" or p["xchannel_masking"] != "on" or "block_channels" in p \
@@ -132,7 +147,7 @@ class cvvdp(vq_metric):
         self.pu_dilate = p["pu_dilate"]
         if self.pu_dilate not in (0, 3):
             raise RuntimeError("pu_dilate must be 0 or 3")
-        self.csf_table = hs.CsfTable(load_config("csf_lut_weber_fixed_size.json", config_paths))
+        self.csf_table = hs.CsfTable(load_config("csf_lut_weber_fixed_size.json", self._config_paths))
         self.jod_a, self.jod_exp = f32(p["jod_a"]), f32(p["jod_exp"])
         self.baseband_weight = np.asarray(p["baseband_weight"], dtype=f32)
         self.ch_w = np.asarray([1.0, p["ch_chrom_w"], p["ch_chrom_w"], p["ch_trans_w"]], dtype=f32)
@@ -173,6 +188,48 @@ class cvvdp(vq_metric):
         if rc != 0:
             raise RuntimeError(f"cvvdp_create failed ({rc})")
         self._params = P
+
+    def update_from_checkpoint(self, ckpt):
+        """cvvdp_metric.py:231-243: take the calibrated parameters out of a training checkpoint -- every `params.<name>` entry of its
+        `state_dict` replaces the parameter <name>; other entries are skipped.  Here the values go into `self.parameters` and the core's handle is re-made, so the next predict() runs with them."""
+        import os
+        assert os.path.isfile(ckpt), f"Calibrated PyTorch checkpoint not found at: {ckpt}"
+        prefix = "params."
+        p = dict(self.parameters)
+        extra = {}
+        for key, value in torch.load(ckpt, map_location=torch.device("cpu"))["state_dict"].items():
+            if not key.startswith(prefix):
+                continue
+            name = key[len(prefix):]
+            v = value.detach().to(torch.float32) if torch.is_tensor(value) else torch.as_tensor(value, dtype=torch.float32)
+            if isinstance(p.get(name), (str, bool)):
+                raise RuntimeError(f"checkpoint entry '{key}' would replace the non-numeric parameter '{name}'")
+            if name in p:
+                p[name] = v.tolist() if v.dim() > 0 else (int(v.item()) if isinstance(p[name], int) else float(v.item()))
+            else:
+                extra[name] = v.to(self.device)        # the reference sets ANY attribute; ones the model does not read stay attributes
+        self._set_parameters(p)
+        for name, v in extra.items():
+            setattr(self, name, v)
+
+    def save_to_config(self, fname, comment):
+        """cvvdp_metric.py:1129-1154: write the current parameters in the layout of the parameter file they were loaded from (strings
+        and integers as loaded, floats and lists from the metric's state), with `__comment` and today's `calibration_date`."""
+        from datetime import date
+        assert fname.endswith(".json"), "Please provide a .json file"
+        parameters = dict(json2dict(self.parameters_file))
+        for key in parameters:
+            if isinstance(parameters[key], (str, int)):
+                continue
+            elif isinstance(parameters[key], float):
+                # the reference holds its trained scalars as fp32 tensors (their .item() is written) and `bfilt_duration` as the plain number
+                parameters[key] = float(self.parameters[key]) if key == "bfilt_duration" else float(np.float64(f32(self.parameters[key])))
+            elif isinstance(parameters[key], list):
+                parameters[key] = [float(x) for x in np.asarray(self.parameters[key], dtype=f32).astype(np.float64)]
+        parameters["__comment"] = comment
+        parameters["calibration_date"] = date.today().strftime("%d/%m/%Y")
+        with open(fname, "w") as f:
+            json.dump(parameters, f, indent=4)
 
     def set_display_model(self, display_name="standard_4k", display_photometry=None, display_geometry=None, config_paths=[]):
         """cvvdp_metric.py:246-264."""

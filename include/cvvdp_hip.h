@@ -145,6 +145,12 @@ int cvvdp_abi_version(void);
  * knobs are read from the environment (CVVDP_SEG_TARGET, CVVDP_R2_SEG, ...: they change launch geometry and with it
  * the last bits of Q_per_ch).  0 for the product build. */
 #define CVVDP_BUILD_DEV_KNOBS 1
+/* CVVDP_BUILD_SAFE_LOADS: the band kernels were compiled with -DCVVDP_SAFE_LOADS (`make safe`: compiler-managed loads, the reference
+ * point of tests/test_safe_loads.py).  CVVDP_BUILD_DIAG: a band kernel was compiled with one of its timing-only switches (S_DIAG_*,
+ * S_PRIO_*: RESULTS ARE WRONG by construction) or a non-default CVVDP_BAND4S_RING.  A binding must refuse a library whose
+ * flags are not 0 unless it was asked for a development library explicitly (colorvideovdp_amd/_capi.py: CVVDP_DEV_KNOBS=1). */
+#define CVVDP_BUILD_SAFE_LOADS 2
+#define CVVDP_BUILD_DIAG 4
 int cvvdp_build_flags(void);
 /* sizeof(cvvdp_params), sizeof(cvvdp_clip) as compiled, so a binding can verify its struct layout. */
 void cvvdp_struct_sizes(int32_t* params_bytes, int32_t* clip_bytes);

@@ -74,6 +74,35 @@ def _device_count():
     return int(p.stdout.strip() or 0)
 
 
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` -- the command shape of the driver's N=1 line, no torch.distributed.run in
+    front -- launches its own two ranks and prints ONE JSON line (gloo + both ranks on device 0: the hooks of this one-GPU box)."""
+    env = dict(os.environ, CVVDP_BENCH_BACKEND="gloo", CVVDP_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", CVVDP_BENCH_SPINUP_S="0.5")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-frames", "0", "--gen", "gpu"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=180, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_total"] == 128 and d["value"] > 0
+    assert [r["rank"] for r in d["config"]["collectives"]["ranks_seen"]] == [0, 1]
+
+
+def test_bench_gpus_n_without_a_launcher_refuses_on_a_smaller_node():
+    """... and on a node with fewer GPUs than N the same command is the one-line refusal, before any launcher or rendezvous."""
+    n = _device_count() + 1
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CVVDP_BENCH_DEVICE", "CVVDP_BENCH_BACKEND"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert p.returncode != 0
+    assert f"needs {n} visible GPUs, this node shows {n - 1}" in p.stdout + p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
 def test_more_ranks_than_gpus_fails_fast_with_one_line():
     """`--gpus N` on a node with fewer than N GPUs (and no test hook that pins the ranks to one device) must not reach a rendezvous,
     set_device on a missing device or RCCL: every rank exits at once with one line that says what is missing."""

@@ -1158,6 +1158,10 @@ def test_device_heatmap_sink_gets_the_same_frames_without_pcie():
     (1200, 144, 3, 60, "standard_4k", "supra-threshold"),      # five strips, three on the split kernel
     (736, 416, 4, 30, "standard_fhd", "threshold"),            # several row segments
     (1446, 333, 2, 60, "standard_hdr_pq", "raw"),              # W % 4 == 2: partial-lane border kernel, odd height
+    # frames on which EVERY strip is a border strip -- the context plane's range (tone curve, clamp) then comes only from the
+    # edge-stream kernel's atomics, which must be ordered after the initialisation of the range words on the main stream
+    (472, 240, 3, 60, "standard_fhd", "threshold"),            # two strips, both at the border
+    (232, 176, 2, 60, "standard_fhd", "supra-threshold"),      # one strip with both borders
 ])
 def test_fused_band_kernels_write_the_heat_map_bands(W, H, F, fps, disp, mode):
     import colorvideovdp_amd as cv

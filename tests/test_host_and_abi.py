@@ -169,3 +169,36 @@ def test_product_library_has_no_development_knobs_and_the_binding_loads_only_it(
     assert out.endswith(os.path.join("colorvideovdp_amd", "libcvvdp_hip.so"))
     out = subprocess.run([sys.executable, "-c", code], env=dict(env, CVVDP_DEV_KNOBS="1"), capture_output=True, text=True, timeout=900).stdout.strip()
     assert out == str(tmp_path / "other.so")
+
+
+def test_a_library_with_a_timing_only_switch_identifies_itself_and_is_refused_as_product(tmp_path):
+    """band4s.hip carries timing-only switches that compute wrong results (S_DIAG_*).  A library compiled with one
+    reports CVVDP_BUILD_DIAG through cvvdp_build_flags() and the binding refuses it unless a development library was asked for; and
+    `make` does not take EXTRA flags from the environment."""
+    import subprocess
+    import sys
+    from colorvideovdp_amd import _capi
+    assert _capi.lib().cvvdp_build_flags() == 0                              # the in-tree product build: nothing compiled in
+    csrc = os.path.join(ROOT, "colorvideovdp_amd", "csrc")
+    # (1) an exported EXTRA changes no compile command of the product build
+    dry = subprocess.run(["make", "-C", csrc, "-n", "-B"], env=dict(os.environ, EXTRA="-DS_DIAG_NOBAR"), capture_output=True, text=True, timeout=120)
+    assert dry.returncode == 0 and "hipcc" in dry.stdout and "S_DIAG_NOBAR" not in dry.stdout
+    dry = subprocess.run(["make", "-C", csrc, "-n", "-B", "EXTRA=-DS_DIAG_NOBAR"], capture_output=True, text=True, timeout=120)
+    assert "S_DIAG_NOBAR" in dry.stdout                                      # (the command line still can: that is explicit)
+    # (2) such a library says what it is, and loads only as a development library
+    p = subprocess.run([os.path.join(ROOT, "tools", "build_variant.sh"), "test_diag_nobar", "band4s.hip", "-DS_DIAG_NOBAR"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    variant = os.path.join(ROOT, "variants", "test_diag_nobar.so")
+    code = ("import sys\nfrom colorvideovdp_amd import _capi\n_capi.LIB_PATH = sys.argv[1]\n"
+            "try:\n    print('flags', _capi.lib().cvvdp_build_flags())\nexcept ImportError as e:\n    print('refused:', e)\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    env.pop("CVVDP_DEV_KNOBS", None)
+    out = subprocess.run([sys.executable, "-c", code, variant], env=env, capture_output=True, text=True, timeout=900).stdout
+    assert out.startswith("refused:") and "not a product build" in out and "= 4" in out
+    out = subprocess.run([sys.executable, "-c", code, variant], env=dict(env, CVVDP_DEV_KNOBS="1"), capture_output=True, text=True, timeout=900).stdout
+    assert out.strip() == f"flags {_capi.BUILD_DIAG}"
+    safe = os.path.join(ROOT, "colorvideovdp_amd", "libcvvdp_hip_safe.so")
+    if os.path.isfile(safe) and os.path.getmtime(safe) >= os.path.getmtime(os.path.join(csrc, "kernels.h")):
+        out = subprocess.run([sys.executable, "-c", code, safe], env=env, capture_output=True, text=True, timeout=900).stdout
+        assert out.startswith("refused:") and "= 2" in out

@@ -9,6 +9,6 @@ R=$(cd $(dirname $0)/.. && pwd); C=$R/colorvideovdp_amd/csrc
 mkdir -p $R/variants/obj
 BAND=""; case $SRC in band*) BAND="-fno-slp-vectorize";; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $BAND "$@" -I$C -x hip -c $C/$SRC -o $R/variants/obj/$NAME.o
-OBJS=$(ls $C/build/*.o | grep -v "/$SRC.o")
+OBJS=$(ls $C/build/*.hip.o $C/build/*.cpp.o | grep -v "/$SRC.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/variants/$NAME.so $OBJS $R/variants/obj/$NAME.o
 echo "variants/$NAME.so"

@@ -70,36 +70,47 @@ __device__ __forceinline__ void s_for_seq(F&& f, std::integer_sequence<int, Us..
 // column sums per cell-row piece; k_feature_finish adds the pieces.  24 more registers in the back waves.
 struct __attribute__((packed, aligned(4))) s_u4 { float x, y, z, w; };     // 16 bytes at 4-byte alignment (rows of W % 4 == 2 frames)
 
+// The block's LDS (a struct handed to the body: the kernel instantiates the body twice -- strips away from the image border and strips AT
+// it -- and function-local __shared__ arrays of two instantiations would be allocated twice)
 template <bool HEAT, bool FEAT>
-__device__ __forceinline__ void band4s_body(const BandArgs& a) {
-  constexpr int NCH = 4, NP = 8;
-  __shared__ __attribute__((aligned(16))) float s_h[HEAT ? NCH : 1][HEAT ? 256 : 4];   // heat-map terms of the pooled row, per channel
+struct S4Lds {
+  static constexpr int NCH = 4, NP = 8;
+  __attribute__((aligned(16))) float s_h[HEAT ? NCH : 1][HEAT ? 256 : 4];   // heat-map terms of the pooled row, per channel
   // FEAT: the column sums of D and D^2 live in LDS (lane-private: no barrier) -- with all 24 sums in registers the back waves spilled
   // eight constants and reloaded three of them per row from scratch (level 0 of 4K x 64: 10.5 ms against 7.2 of the plain kernel)
-  __shared__ __attribute__((aligned(16))) float s_fd[2][FEAT ? NCH : 1][FEAT ? 256 : 4];
-  __shared__ __attribute__((aligned(16))) float2 s_ve[2][NP][S_VE / 2];
-  __shared__ __attribute__((aligned(16))) float s_g[2][NP][256];             // raw level-l row handed from the front to the back (by row parity)
-  __shared__ __attribute__((aligned(16))) float s_lum[2][256];               // 1/L_T, 1/L_R
-  __shared__ __attribute__((aligned(16))) float s_S[NCH][256];
-  __shared__ __attribute__((aligned(16))) float s_m[NCH][256];
-  __shared__ __attribute__((aligned(16))) float s_q[NCH][256];
-  __shared__ __attribute__((aligned(16))) float s_d[S_R + 1][NCH][S_SW];     // lane-private ring of |T'-R'| + eps
-  __shared__ __attribute__((aligned(8))) float2 s_lut[NCH][CVVDP_CSF_NODES];
+  __attribute__((aligned(16))) float s_fd[2][FEAT ? NCH : 1][FEAT ? 256 : 4];
+  __attribute__((aligned(16))) float2 s_ve[2][NP][S_VE / 2];
+  __attribute__((aligned(16))) float s_g[2][NP][256];             // raw level-l row handed from the front to the back (by row parity)
+  __attribute__((aligned(16))) float s_lum[2][256];               // 1/L_T, 1/L_R
+  __attribute__((aligned(16))) float s_S[NCH][256];
+  __attribute__((aligned(16))) float s_m[NCH][256];
+  __attribute__((aligned(16))) float s_q[NCH][256];
+  __attribute__((aligned(16))) float s_d[S_R + 1][NCH][S_SW];     // lane-private ring of |T'-R'| + eps
+  __attribute__((aligned(16))) float2 s_lut[NCH][CVVDP_CSF_NODES];
+};
+
+// EDGE (round 5): the strips that touch the image's left or right border, W % 4 == 0 (band4f.hip EDGE == 1: zero masks of the reduce's
+// padding, the first / last column's extra taps, coarse-column replicas by lane reads, the blur's reflect padding written as mirrors,
+// lanes outside the image masked out).  The front waves have the registers for it, so these strips keep the hand-managed loads and
+// the front / back layout -- until round 4 they ran k_band4f<4, 1> (245 VGPRs, two waves per SIMD) as a second launch beside this
+// kernel, and at levels 1 and 2 that launch took as long as all other strips together (profiles/r04_dev_notes.txt 10).
+template <bool HEAT, bool FEAT, bool EDGE>
+__device__ __forceinline__ void band4s_body(const BandArgs& a, S4Lds<HEAT, FEAT>& L, const int strip, const int seg, const int item) {
+  constexpr int NCH = 4, NP = 8;
+  auto& s_h = L.s_h; auto& s_fd = L.s_fd; auto& s_ve = L.s_ve; auto& s_g = L.s_g; auto& s_lum = L.s_lum; auto& s_S = L.s_S;
+  auto& s_m = L.s_m; auto& s_q = L.s_q; auto& s_d = L.s_d; auto& s_lut = L.s_lut;
 
   const int t = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const bool front = wv < NCH;
   const int c = wv & (NCH - 1);
   const int j = t & 63;
-  const int per_xcd = a.per_xcd;
-  const int wu = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);      // XCD-aware work-unit order (band4.hip)
-  if (wu >= a.n_strip_l * a.n_seg * a.items) return;
-  const int sl = wu % a.n_strip_l, seg = (wu / a.n_strip_l) % a.n_seg, item = wu / (a.n_strip_l * a.n_seg);
-  const int strip = a.strip0 + sl;
   const int H = a.H, W = a.W, Hc = a.Hc, Wc = a.Wc;
   const int x0 = strip * S_SW;
   const int fc0 = x0 - S_HALO + 4 * j;
-  const bool interior = j >= 2 && j < 62;
+  const bool in_img = !EDGE || (fc0 >= 0 && fc0 < W);
+  const bool edge_r = EDGE && x0 + S_SW + S_HALO > W;
+  const bool interior = j >= 2 && j < 62 && (!EDGE || fc0 < W);
   const int cb = (x0 - S_HALO) / 2;
   const int ys = seg * a.seg_h, ye = min(H, ys + a.seg_h);
   const bool top_seg = seg == 0;
@@ -135,7 +146,13 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
     // own four columns; the neighbour samples (columns fc0-2, fc0-1 and fc0+4) sit at immediate offsets -8 / +16 from them: the strips
     // that run here stay clear of the image's left / right border (x0 >= 240, x0 + 248 <= W), so nothing is clamped or masked.  Column
     // fc0+4 of the last lane may be column W, i.e. the next row's first sample: it only enters coarse columns beyond the blur halo.
-    const uint32_t goff = (uint32_t)fc0 * 4u;
+    // EDGE: addresses are clamped into the row (samples outside the image are the reference's zero padding: the loaded values are
+    // multiplied by 0 in consume), so the neighbour samples need offset registers of their own
+    const uint32_t goff = (uint32_t)(EDGE ? min(max(fc0, 0), W - 4) : fc0) * 4u;
+    const uint32_t loff = EDGE ? (uint32_t)min(max(fc0 - 2, 0), W - 2) * 4u : goff;       // columns fc0-2, fc0-1 (EDGE == 0: goff - 8 as an immediate)
+    const uint32_t roff = EDGE ? (uint32_t)min(max(fc0 + 4, 0), W - 1) * 4u : goff;       // column fc0+4 (EDGE == 0: goff + 16)
+    const int lane_first = 2;                                        // strip 0: the lane of fine column 0
+    const int lane_last = (W - 4 - (x0 - S_HALO)) >> 2;              // edge_r strips: the lane of the last four fine columns (0 .. 63)
 
     float4 cA = make_float4(0, 0, 0, 0), cB = cA, cC = cA;          // coarse rows my-1, my, my+1 of this lane's two coarse columns: (T0, T1, R0, R1)
     float4 rP = cA, rQ = cA;                                        // partial sums of the two coarse rows under construction (older, younger)
@@ -159,11 +176,31 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
     // One level-l row (four own samples + three neighbours per plane) through the horizontal pass, then into the running sums
     // (band4f.hip consume, EDGE == 0).  a_row: its index (scalar).  Even rows complete coarse row a_row/2 - 1 -> emitted.
     auto consume = [&](int a_row, auto odd_a, v4f vT, v4f vR, v2f lT, float rT, v2f lR, float rR, float4& emitted) {
+      if constexpr (EDGE) {
+        // Zero padding left / right of the image (band4f.hip consume, EDGE == 1: there every sample is multiplied by a lane mask).  Only
+        // two lanes hold coarse columns INSIDE the image that see samples outside it -- the lane of column 0 (its left neighbours) and the
+        // lane of columns W-4 .. W-1 (its right neighbour); the coarse columns of the lanes outside the image are replaced by replicas
+        // below, whatever they were.  So two exec-masked moves instead of masks: no per-lane constants live across the row loop.
+        if (strip == 0 && j == lane_first) { lT = v2f{0.0f, 0.0f}; lR = v2f{0.0f, 0.0f}; }
+        if (edge_r && j == lane_last) { rT = 0.0f; rR = 0.0f; }
+      }
       float4 hr;
       hr.x = __builtin_fmaf(vT.z, rk4, __builtin_fmaf(vT.y, rk3, __builtin_fmaf(vT.x, rk2, __builtin_fmaf(lT.y, rk1, lT.x * rk0))));
       hr.y = __builtin_fmaf(rT, rk4, __builtin_fmaf(vT.w, rk3, __builtin_fmaf(vT.z, rk2, __builtin_fmaf(vT.y, rk1, vT.x * rk0))));
       hr.z = __builtin_fmaf(vR.z, rk4, __builtin_fmaf(vR.y, rk3, __builtin_fmaf(vR.x, rk2, __builtin_fmaf(lR.y, rk1, lR.x * rk0))));
       hr.w = __builtin_fmaf(rR, rk4, __builtin_fmaf(vR.w, rk3, __builtin_fmaf(vR.z, rk2, __builtin_fmaf(vR.y, rk1, vR.x * rk0))));
+      if constexpr (EDGE) {
+        // first / last output column (lpyr_dec.py:205-209; the last column's extra taps depend on the ROW parity, sic): the same two lanes
+        if (strip == 0 && j == lane_first) {
+          hr.x = __builtin_fmaf(vT.y, rk0, __builtin_fmaf(vT.x, rk1, hr.x));
+          hr.z = __builtin_fmaf(vR.y, rk0, __builtin_fmaf(vR.x, rk1, hr.z));
+        }
+        if (edge_r && j == lane_last) {                               // columns W-2, W-1: the lane's second coarse column
+          const float wr3 = (H & 1) ? rk3 : rk4, wr2 = (H & 1) ? rk4 : 0.0f;
+          hr.y = __builtin_fmaf(vT.z, wr2, __builtin_fmaf(vT.w, wr3, hr.y));
+          hr.w = __builtin_fmaf(vR.z, wr2, __builtin_fmaf(vR.w, wr3, hr.w));
+        }
+      }
       const bool ok = a_row >= 0 && a_row < H;
       const bool border = a_row <= 1 || a_row >= H - 2;               // (scalar)
       auto axpy = [](float4& y, const float4& x, float w) {
@@ -193,6 +230,18 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
         rQ = ok ? make_float4(hr.x * rk0, hr.y * rk0, hr.z * rk0, hr.w * rk0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         const int m1 = (a_row >> 1) - 1;                             // the coarse row just completed
         if (m1 > Hc - 1) emitted = cC;                               // below the last coarse row: its replica (the expand clamps)
+        if constexpr (EDGE) {                                        // coarse columns outside the image: replicas of column 0 / Wc-1
+          if (strip == 0) {
+            const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, emitted.x), lane_first));
+            const float r0_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, emitted.z), lane_first));
+            if (fc0 < 0) emitted = make_float4(t0, t0, r0_, r0_);
+          }
+          if (edge_r) {
+            const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, emitted.y), lane_last));
+            const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, emitted.w), lane_last));
+            if (fc0 >= W) emitted = make_float4(t1, t1, r1, r1);
+          }
+        }
         // level l+1 belongs to the lanes that own its columns (interior of the strip) in the segment that owns its rows
         const int own_end = seg == a.n_seg - 1 ? Hc : (ye >> 1);
         if (interior && m1 >= (ys >> 1) && m1 < own_end) {
@@ -243,8 +292,15 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
     //   phase 2 of step s:  neighbour samples of row s+7 (4 loads) -> set (s+7) & 1,  rows s+S_RING+1 of the two planes (2 loads)
     //   start of step s:    needs ring slot (s+5) % S_RING and neighbour set (s+5) & 1; younger than those: the 2 row loads of step
     //                       s-2, the 6 loads of step s-1 -> vmcnt(8)   (stores count too: that only makes the wait stricter)
-    constexpr int S_RING = CVVDP_BAND4S_RING;
-    static_assert(S_RING >= 8 && S_RING % 2 == 0, "vmcnt(8) of the row step assumes rows s+6.. are older than the neighbour set of row s+5");
+    // EDGE: a ring of six rows (rows s+6, s+7 in flight during step s, as in k_band4f) -- the border code costs the front ~14 registers
+    // and the kernel must stay under 128 for four waves per SIMD.  In general: at the start of step s the youngest loads that must have
+    // landed are the row loads of step s-(S_RING-4)/2 ... which leaves exactly S_RING younger ones -> vmcnt(S_RING)
+#ifdef S_DIAG_EDGE_RING     // A/B: the border body's ring length
+    constexpr int S_RING = EDGE ? S_DIAG_EDGE_RING : CVVDP_BAND4S_RING;
+#else
+    constexpr int S_RING = EDGE ? 6 : CVVDP_BAND4S_RING;
+#endif
+    static_assert(S_RING >= 6 && S_RING % 2 == 0, "the row step's wait count assumes the ring slot of row s+5 and the neighbour set of row s+5 are older than S_RING loads");
     v4f ringT[S_RING], ringR[S_RING];
     v2f nbLT[2], nbLR[2];
     float nbRT[2], nbRR[2];
@@ -258,19 +314,20 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
     struct __attribute__((packed, aligned(4))) u4 { float x, y, z, w; };     // (rows of W % 4 == 2 frames are 8-byte aligned)
     struct __attribute__((packed, aligned(4))) u2 { float x, y; };
 #define S_LOAD4(dst, off, plane, row) do { const u4 q_ = *reinterpret_cast<const u4*>(S_ROWPTR(plane, row, off)); dst = v4f{q_.x, q_.y, q_.z, q_.w}; } while (0)
-#define S_LOADL(dst, off, plane, row) do { const u2 q_ = *reinterpret_cast<const u2*>(S_ROWPTR(plane, row, off) - 8); dst = v2f{q_.x, q_.y}; } while (0)
-#define S_LOADR(dst, off, plane, row) dst = *reinterpret_cast<const float*>(S_ROWPTR(plane, row, off) + 16)
+#define S_LOADL(dst, plane, row) do { const u2 q_ = *reinterpret_cast<const u2*>(S_ROWPTR(plane, row, loff) - (EDGE ? 0 : 8)); dst = v2f{q_.x, q_.y}; } while (0)
+#define S_LOADR(dst, plane, row) dst = *reinterpret_cast<const float*>(S_ROWPTR(plane, row, roff) + (EDGE ? 0 : 16))
 #define S_WAIT8(...) do { } while (0)
 #else
 #define S_LOAD4(dst, off, plane, row) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W))
-#define S_LOADL(dst, off, plane, row) asm volatile("global_load_dwordx2 %0, %1, %2 offset:-8" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W))
-#define S_LOADR(dst, off, plane, row) asm volatile("global_load_dword %0, %1, %2 offset:16" : "+v"(dst) : "v"(off), "s"((plane) + (int64_t)(row) * W))
+#define S_LOADL(dst, plane, row) do { if constexpr (EDGE) asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(dst) : "v"(loff), "s"((plane) + (int64_t)(row) * W)); \
+    else asm volatile("global_load_dwordx2 %0, %1, %2 offset:-8" : "+v"(dst) : "v"(goff), "s"((plane) + (int64_t)(row) * W)); } while (0)
+#define S_LOADR(dst, plane, row) do { if constexpr (EDGE) asm volatile("global_load_dword %0, %1, %2" : "+v"(dst) : "v"(roff), "s"((plane) + (int64_t)(row) * W)); \
+    else asm volatile("global_load_dword %0, %1, %2 offset:16" : "+v"(dst) : "v"(goff), "s"((plane) + (int64_t)(row) * W)); } while (0)
 #ifdef S_DIAG_NO_NB
-#define S_WAITN "s_waitcnt vmcnt(4)"
+#define S_WAIT8(a0, a1, a2, a3, a4, a5) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : "n"(S_RING - 4))
 #else
-#define S_WAITN "s_waitcnt vmcnt(8)"
+#define S_WAIT8(a0, a1, a2, a3, a4, a5) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5) : "n"(S_RING))
 #endif
-#define S_WAIT8(a0, a1, a2, a3, a4, a5) asm volatile(S_WAITN : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5))
 #endif
     // (the drain names every register a load may still be heading for: without that use the compiler sees the last rows' loads as dead
     // values and hands their registers to temporaries while the loads are in flight)
@@ -284,11 +341,11 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
     auto rowc = [&](int r) { return min(max(r, 0), H - 1); };       // rows outside the image: any valid row (their weight is 0)
     auto load_nb = [&](auto p_, int row) {
       constexpr int PS = decltype(p_)::value;
-      (void)&nbLT; (void)&nbLR; (void)&nbRT; (void)&nbRR; (void)&goff; (void)&gT; (void)&gR; (void)&W;   // (asm operands alone do not capture)
-      S_LOADL(nbLT[PS], goff, gT, row);
-      S_LOADR(nbRT[PS], goff, gT, row);
-      S_LOADL(nbLR[PS], goff, gR, row);
-      S_LOADR(nbRR[PS], goff, gR, row);
+      (void)&nbLT; (void)&nbLR; (void)&nbRT; (void)&nbRR; (void)&goff; (void)&loff; (void)&roff; (void)&gT; (void)&gR; (void)&W;   // (asm operands alone do not capture)
+      S_LOADL(nbLT[PS], gT, row);
+      S_LOADR(nbRT[PS], gT, row);
+      S_LOADL(nbLR[PS], gR, row);
+      S_LOADR(nbRR[PS], gR, row);
     };
 
     // ---- prologue: rows r_start-4 .. r_start+4 prime the reduce (three complete coarse rows in the window, two partial ones),
@@ -297,8 +354,8 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
       auto ld4 = [&](const float* plane, int r) -> v4f {
         return *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(plane + (int64_t)rowc(r) * W) + goff);
       };
-      auto ld2 = [&](const float* plane, int r) -> v2f { return *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(plane + (int64_t)rowc(r) * W) + goff - 8); };
-      auto ld1 = [&](const float* plane, int r) -> float { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane + (int64_t)rowc(r) * W) + goff + 16); };
+      auto ld2 = [&](const float* plane, int r) -> v2f { return *reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(plane + (int64_t)rowc(r) * W) + loff - (EDGE ? 0 : 8)); };
+      auto ld1 = [&](const float* plane, int r) -> float { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane + (int64_t)rowc(r) * W) + roff + (EDGE ? 0 : 16)); };
       float4 em = cC;
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
@@ -341,7 +398,7 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
       constexpr int U = decltype(u_)::value;
       constexpr bool ODD = (U & 1) != 0;
       constexpr int S5 = (U + 5) % S_RING, S1 = (U + 1) % S_RING, P5 = (U + 5) & 1;
-      (void)&ringT; (void)&ringR; (void)&nbLT; (void)&nbLR; (void)&nbRT; (void)&nbRR; (void)&goff; (void)&gT; (void)&gR; (void)&W;
+      (void)&ringT; (void)&ringR; (void)&nbLT; (void)&nbLR; (void)&nbRT; (void)&nbRR; (void)&goff; (void)&loff; (void)&roff; (void)&gT; (void)&gR; (void)&W;
       S_WAIT8(ringT[S5], ringR[S5], nbLT[P5], nbLR[P5], nbRT[P5], nbRR[P5]);
       // ================= phase 1: level-l row r+5 into the reduce; an even row completes a coarse row, which rolls the window for row r+1
       float4 emitted = cC;
@@ -505,7 +562,7 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
     auto heat_row = [&](int y) {
       if constexpr (HEAT) {
         const int col = t - 64 * NCH;
-        if (y >= ys && col >= S_HALO && col < 256 - S_HALO) {
+        if (y >= ys && col >= S_HALO && col < 256 - S_HALO && (!EDGE || x0 - S_HALO + col < W)) {
           const float sum = (s_h[0][col] + s_h[1][col] + s_h[2][col]) + s_h[3][col];
           a.dchr[(int64_t)item * ((int64_t)H * W) + (int64_t)y * W + (x0 - S_HALO + col)] = (fast_pow(sum + kEps, inv_beta_tch) - eps_inv_btch) / a.band_mul;
         }
@@ -546,7 +603,7 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
       if (interior && yprev >= ys) stage3c(k7);
       feat_d_row(yprev);
       const bool feat_row = FEAT && r >= ys && r < ye;  // (scalar) row r belongs to this segment: its |T'|, |R'| are counted
-      {
+      if (in_img) {                                     // (EDGE == 0: every lane)
         float exT[4], exR[4];
         expand4(s_ve[ODD][2 * c], exT);
         expand4(s_ve[ODD][2 * c + 1], exR);
@@ -590,6 +647,20 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
               const v2f at2 = {at4[2 * h], at4[2 * h + 1]}, ar2 = {ar4[2 * h], ar4[2 * h + 1]};
               f_t[h] += at2; f_t2[h] += at2 * at2; f_r[h] += ar2; f_r2[h] += ar2 * ar2;
             }
+          }
+        }
+        if constexpr (EDGE) {
+          // the blur's reflect padding at the left / right image border (band4f.hip, mirror roles): the lanes of columns 1..6 / W-7..W-2
+          // write their samples a second time at the mirrored positions of this wave's s_m row (column x <-> -x, 2(W-1)-x)
+          if (strip == 0) {
+            if (j == 2) { float* dst = &s_m[c][S_HALO - 1]; dst[0] = m[1]; dst[-1] = m[2]; dst[-2] = m[3]; }          // columns 1, 2, 3 -> -1, -2, -3
+            if (j == 3) { float* dst = &s_m[c][S_HALO - 4]; dst[0] = m[0]; dst[-1] = m[1]; dst[-2] = m[2]; }          // columns 4, 5, 6 -> -4, -5, -6
+          }
+          if (edge_r) {
+            const int ll = (W - 4 - (x0 - S_HALO)) >> 2;              // the lane of columns W-4 .. W-1 (scalar)
+            const int e = 2 * (W - 1) - (x0 - S_HALO);                // s_m index of the mirror of column 0 + the column
+            if (j == ll - 1 && e - (W - 7) < 256) { float* dst = &s_m[c][e - (W - 7)]; dst[0] = m[1]; dst[-1] = m[2]; dst[-2] = m[3]; }   // W-7, W-6, W-5
+            if (j == ll && e - (W - 4) < 256) { float* dst = &s_m[c][e - (W - 4)]; dst[0] = m[0]; dst[-1] = m[1]; dst[-2] = m[2]; }       // W-4, W-3, W-2
           }
         }
       }
@@ -698,11 +769,34 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a) {
 #endif
 }
 
-__global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) { band4s_body<false, false>(a); }
-__global__ __launch_bounds__(512, 4) void k_band4s_heat(BandArgs a) { band4s_body<true, false>(a); }
-__global__ __launch_bounds__(512, 4) void k_band4s_feat(BandArgs a) { band4s_body<false, true>(a); }
+// One launch per level: every strip of the level, the work units dealt to the launch indices so that the blocks resident on one XCD are
+// neighbouring strips of the same rows (band4.hip).  Strips at the image's left / right border take the EDGE instantiation of the body
+// (a block-uniform branch), all others the border-free one.  W % 4 == 2 frames keep band4f.hip's partial-lane kernel for their border strips
+// (launch_band4f: a.edge_in_s == 0, strips strip0 .. strip0 + n_strip_l - 1 are then all border-free).
+template <bool HEAT, bool FEAT>
+__device__ __forceinline__ void band4s_kernel(const BandArgs& a) {
+  __shared__ S4Lds<HEAT, FEAT> lds;
+  const int per_xcd = a.per_xcd;
+  const int wu = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);      // XCD-aware work-unit order (band4.hip)
+  if (wu >= a.n_strip_l * a.n_seg * a.items) return;
+  const int sl = wu % a.n_strip_l, seg = (wu / a.n_strip_l) % a.n_seg, item = wu / (a.n_strip_l * a.n_seg);
+  const int strip = a.strip0 + sl;
+#ifdef S_DIAG_EDGE_OFF      // timing only: the border strips on the border-free body (their results are wrong)
+  const bool edge = false;
+#else
+  const bool edge = !FEAT && a.edge_in_s && (strip == 0 || strip * S_SW + S_SW + S_HALO > a.W);
+#endif
+  // (FEAT: the back waves' 16 sum registers leave no room for the border code -- both bodies in one kernel spill the front's ring; features
+  // clips keep k_band4f_feat<4, 1> for their border strips, launch_band4f)
+  if constexpr (!FEAT) {
+    if (edge) { band4s_body<HEAT, FEAT, true>(a, lds, strip, seg, item); return; }
+  }
+  band4s_body<HEAT, FEAT, false>(a, lds, strip, seg, item);
+}
+__global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) { band4s_kernel<false, false>(a); }
+__global__ __launch_bounds__(512, 4) void k_band4s_heat(BandArgs a) { band4s_kernel<true, false>(a); }
+__global__ __launch_bounds__(512, 4) void k_band4s_feat(BandArgs a) { band4s_kernel<false, true>(a); }
 
-// the strips away from the image's left / right border of a fused level (launch_band4f deals them: strip0 .. strip0 + n_strip_l - 1)
 void launch_band4s(const BandArgs& a, hipStream_t s) {
   if (a.fsum) hipLaunchKernelGGL(k_band4s_feat, dim3(8 * a.per_xcd), dim3(512), 0, s, a);
   else if (a.dchr) hipLaunchKernelGGL(k_band4s_heat, dim3(8 * a.per_xcd), dim3(512), 0, s, a);
@@ -715,7 +809,7 @@ int tu_flags_band4s() {
   f |= CVVDP_BUILD_SAFE_LOADS;
 #endif
 #if defined(S_DIAG_NOBAR) || defined(S_DIAG_BACK_ONLY) || defined(S_DIAG_FRONT_ONLY) || defined(S_DIAG_NO_STORE) || defined(S_DIAG_PLAIN_STORE) || \
-    defined(S_DIAG_NO_NB) || defined(S_DIAG_NO_SG) || defined(S_DIAG_NO_LUM) || defined(S_PRIO_FRONT) || defined(S_PRIO_BACK) || CVVDP_BAND4S_RING != 8
+    defined(S_DIAG_NO_NB) || defined(S_DIAG_NO_SG) || defined(S_DIAG_EDGE_OFF) || defined(S_DIAG_EDGE_RING) || defined(S_DIAG_NO_LUM) || defined(S_PRIO_FRONT) || defined(S_PRIO_BACK) || CVVDP_BAND4S_RING != 8
   f |= CVVDP_BUILD_DIAG;
 #endif
   return f;

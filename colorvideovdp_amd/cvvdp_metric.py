@@ -399,9 +399,12 @@ class cvvdp(vq_metric):
             pieces_ok = device_raw and self.do_heatmap and getattr(self, "_feature_out", None) is None
             if pieces_ok:
                 piece = self._piece_frames()
-                fixed_p = fixed + piece * (pix * batch * (2 * nch * 4 * 0.34) + pix * 16)
+                fixed_p = fixed + piece * (pix * batch * (2 * nch * 4 * 0.34) + pix * 16) + piece * 8192     # (+ the range / tone-curve words of a piece)
                 nb_abs = int((_total * 0.30 - fixed_p) // (pix * batch * 2 * nch * 4))
-                nb = max(piece, min(int((budget - fixed_p) // (pix * batch * 2 * nch * 4)), nb_abs, 64))
+                nb_long = min(int((budget - fixed_p) // (pix * batch * 2 * nch * 4)), nb_abs, 64)
+                # a long block pays only when it is longer than a piece; otherwise (a small gpu_mem cap, little free memory) the plain
+                # 16-frame-block rule applies, so that the budget stays a hard cap (it used to be clamped UP to the piece)
+                nb = nb_long if nb_long > piece else min(nb, 16)
             else:
                 nb = min(nb, 16 if self.do_heatmap else (_capi.MAX_WINDOW - fl + 1 if long_ok else 64))
             if host_resident and n_frames > 24:

@@ -22,12 +22,14 @@
  *     HIP objects, created lazily on first use and destroyed with the handle: up to three non-blocking helper
  *     streams with their fork / join events -- two for the small pyramid levels of images and short blocks, which
  *     run beside level 0, and an edge stream on which the border strips of a level run beside its border-free
- *     strips (fused band kernels; the edge strips of large ragged frames); the caller's stream waits for them
+ *     strips (fused levels of W % 4 == 2 frames and of features clips; the edge strips of large ragged frames); the caller's stream waits for them
  *     by event before anything reads the results -- and, while profiling is enabled, timing events.
  *   - scores do not depend on how a clip is cut into blocks or shards (bit for bit), but the band kernels a level
- *     runs on depend on what else is asked for: the fused kernels serve plain scoring only, so Q_per_ch / JOD of
- *     one clip with and without a heat map (or features, or the dump) agree to rounding (observed <= 5e-5 relative
- *     in Q_per_ch), not bit for bit.  cvvdp_clip.fuse_mode = 2 pins the unfused route for callers who need equality.
+ *     runs on depend on what else is asked for: plain scoring, heat maps and features have their own kernels on the
+ *     fused route (k_band4s / _heat / _feat; features keep k_band4f_feat on the border strips) and the debug dump runs
+ *     the unfused route (reduce pass + k_band4), so Q_per_ch / JOD of one clip with and without a heat map (or features,
+ *     or the dump) agree to rounding (observed <= 5e-5 relative in Q_per_ch), not bit for bit.  cvvdp_clip.fuse_mode = 2
+ *     pins the unfused route for callers who need equality.
  *   - the library reads no environment variable (tuning knobs exist only in a -DCVVDP_DEV_KNOBS build,
  *     cvvdp_build_flags()).
  *   - "item" = one (frame-in-block, batch) pair; item index = frame * batch + b.
@@ -260,7 +262,10 @@ int cvvdp_get_heatmap(cvvdp_handle* h, int32_t n_frames, void* dev_out_f16, void
  * to bring to the host, and nothing left to convert there. */
 int cvvdp_get_heatmap_rgb8(cvvdp_handle* h, int32_t n_frames, void* dev_out_u8, void* stream);
 
-/* Test/inspection: device pointer + element count of an internal buffer (level where relevant). */
+/* Test/inspection: device pointer + element count of an internal buffer (level where relevant).  CVVDP_BUF_HEAT: level l holds the
+ * heat-map reconstruction from the coarsest level up to l (lpyr_dec.py:328-335) -- EXCEPT level 0 of frames with at least two pyramid
+ * levels and W % 4 == 0: there the last step (level 1 -> 0) is done inside the finishing kernels (cvvdp_get_heatmap*), so level 0 holds
+ * the bare level-0 band and the full reconstruction never exists as a plane. */
 int cvvdp_debug_buffer(cvvdp_handle* h, int32_t which, int32_t level, void** dev_ptr, size_t* n_floats);
 
 /* Profiling aid for bench.py: when enabled, the core brackets every kernel launch with hipEvents on

@@ -22,7 +22,7 @@ def _names(pattern):
 
 def golden_cases():
     """Array-input cases made by oracle/make_goldens.py."""
-    return [n for n in _names("*.npz") if n != "setup" and not n.startswith(("yuv", "fullsize", "kat_", "bench_", "deep_", "outputs", "features", "resize_", "fuzz_"))]
+    return [n for n in _names("*.npz") if n != "setup" and not n.startswith(("yuv", "fullsize", "kat_", "bench_", "deep_", "outputs", "features", "resize_", "fuzz_", "checkpoint"))]
 
 
 def yuv_cases():

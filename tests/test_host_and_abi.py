@@ -202,3 +202,19 @@ def test_a_library_with_a_timing_only_switch_identifies_itself_and_is_refused_as
     if os.path.isfile(safe) and os.path.getmtime(safe) >= os.path.getmtime(os.path.join(csrc, "kernels.h")):
         out = subprocess.run([sys.executable, "-c", code, safe], env=env, capture_output=True, text=True, timeout=900).stdout
         assert out.startswith("refused:") and "= 2" in out
+
+
+def test_heatmap_block_policy_keeps_gpu_mem_a_hard_cap(monkeypatch):
+    """for heat-map clips resident in HBM the block length was clamped UP to the 16-frame piece even when the user's gpu_mem
+    cap (or the free memory) allowed fewer frames.  The long-block rule now applies only when it yields more than a piece."""
+    import torch
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (int(200e9), int(288e9)))
+    m = cv.cvvdp(display_name="standard_4k", heatmap="threshold")
+    pix8k, pix_fhd = 7680 * 4320, 1920 * 1080
+    big = m._pick_block_frames(pix8k, 1, 256, 17, 4, False, True)
+    assert 16 < big <= 64                                     # plenty of memory: a long temporal block scored in 16-frame pieces
+    m.gpu_mem = 6.0                                           # 6 GB: an 8K frame's planes alone are ~1.4 GB
+    capped = m._pick_block_frames(pix8k, 1, 256, 17, 4, False, True)
+    per_frame = pix8k * (2 * 4 * 4 * 1.34) + pix8k * 16
+    assert capped < 16 and capped * per_frame <= 6.0e9
+    assert m._pick_block_frames(pix_fhd, 1, 256, 17, 4, False, True) == 64      # the same cap is no constraint at 1080p

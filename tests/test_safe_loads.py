@@ -44,7 +44,7 @@ def test_product_build_computes_what_the_compiler_scheduled_build_computes(tmp_p
         for route in ("unfused", "fused_one_wave", "fused_split"):
             assert {f"{name}.{route}.{x}" for x in ("jod", "q", "fused_levels", "g1", "g2")} <= set(keys)
         assert f"{name}.heat.map" in keys and f"{name}.heat.q" in keys and int(mine[f"{name}.feat.n_bands"]) >= 8
-    assert int(mine["full_4k64.fused_split.fused_levels"]) == 3
+    assert int(mine["full_4k64.fused_split.fused_levels"]) >= 3      # (fuse_mode 1 fuses every level that can be; the product picks 3 here)
     for k in keys:
         np.testing.assert_array_equal(mine[k], safe[k], err_msg=k)
     # the routes that were asked for did run

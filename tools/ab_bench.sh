@@ -1,10 +1,11 @@
 #!/bin/bash
 # A/B of library variants on one box: tools/ab_bench.sh <tag> [variant.so ...]   (run through gpurun from the repo root)
-# Prints the per-kernel milliseconds of the 4K x 64 bench step for the in-tree library and for each variant.
+# Prints the per-kernel milliseconds of the bench step (WORKLOAD, default 4k64) for the in-tree library and for each variant.
 TAG=${1:-ab}; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
+WL=${WORKLOAD:-4k64}
 run() { # name, lib
-  CVVDP_DEV_KNOBS=1 CVVDP_LIB=$2 timeout 600 python bench.py --steps 10 --warmup 3 --cpu-frames 0 > $OUT/$1.json 2> $OUT/$1.err
+  CVVDP_DEV_KNOBS=1 CVVDP_LIB=$2 timeout 600 python bench.py --workload $WL --steps 10 --warmup 3 --cpu-frames 0 --no-power-probe $BENCH_ARGS > $OUT/$1.json 2> $OUT/$1.err
   python - "$OUT/$1.json" "$1" <<'PY'
 import json,sys
 try:

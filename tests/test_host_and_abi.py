@@ -208,6 +208,7 @@ def test_heatmap_block_policy_keeps_gpu_mem_a_hard_cap(monkeypatch):
     """for heat-map clips resident in HBM the block length was clamped UP to the 16-frame piece even when the user's gpu_mem
     cap (or the free memory) allowed fewer frames.  The long-block rule now applies only when it yields more than a piece."""
     import torch
+    import colorvideovdp_amd as cv
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (int(200e9), int(288e9)))
     m = cv.cvvdp(display_name="standard_4k", heatmap="threshold")
     pix8k, pix_fhd = 7680 * 4320, 1920 * 1080

@@ -461,7 +461,10 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
       const int clip_frames = c.total_frames > 0 ? c.total_frames : 64;
       static const int target_env = dev_knob("CVVDP_SEG_TARGET", 0);
       static const int rows_env = dev_knob("CVVDP_SEG_ROWS", 0);
-      const int nominal = c.is_video ? std::min(64, clip_frames) : 1, target = target_env > 0 ? target_env : 768;
+      // heat-map clips run their band stage on 16 frames at a time (16-frame blocks, or 16-frame pieces of a long temporal block --
+      // whatever score_frames says, so that results do not depend on it): sized for 64, their small levels left most of the GPU idle
+      // (8K, level 3: 72 workgroups per launch)
+      const int nominal = c.is_video ? std::min(c.heatmap != CVVDP_HEATMAP_NONE ? 16 : 64, clip_frames) : 1, target = target_env > 0 ? target_env : 768;
       const int max_rows = rows_env > 0 ? rows_env : (c.is_video ? 384 : 256);
       const int per_seg = lv.n_strip * nominal * c.batch;
       const int want = (target + per_seg - 1) / per_seg;
@@ -503,6 +506,30 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
              band4f_supported(h->lv[h->fuse_levels].H, h->lv[h->fuse_levels].W) &&
              (c.fuse_mode == 1 || (int64_t)h->lv[h->fuse_levels].P * nominal * c.batch >= (int64_t)1 << 24))
         ++h->fuse_levels;
+  }
+  // Row segments of the fused levels, round 5.  k_band4s runs 512-thread blocks, two per CU: 512 resident workgroups, and a level takes
+  // (rounds of 512) x (one block's march).  The 768-block target above is k_band4's (three 256-thread blocks per CU); on a fused level it
+  // produced 1.5 rounds where one would do -- 4K level 2 and 1080p level 1: 3 segments of 180 rows = 768 workgroups = two rounds of 201
+  // row steps, against 2 segments of 270 rows = 512 workgroups = one round of 291.  So: among the segment counts the row limit allows,
+  // the one with the fewest row steps in sequence (21 = blur halo + reduce prologue rows per segment); from the nominal block, like
+  // everything else that decides a frame's summation order.
+  {
+    const int clip_frames = c.total_frames > 0 ? c.total_frames : 64;
+    const int nominal = c.is_video ? std::min(c.heatmap != CVVDP_HEATMAP_NONE ? 16 : 64, clip_frames) : 1;
+    static const int seg_rule = dev_knob("CVVDP_FUSED_SEG_RULE", 1);
+    for (int l = 0; seg_rule && c.fuse_mode != 1 && l < h->fuse_levels; ++l) {
+      Level& lv = h->lv[l];
+      const int64_t per_seg = (int64_t)lv.n_strip * nominal * c.batch;
+      const int lo = (lv.H + 383) / 384, hi = std::max(lo, (lv.H + 47) / 48);      // (segments of at least 48 rows: 21 of them are overhead)
+      int64_t best_cost = -1; int best_n = lv.n_seg, best_h = lv.seg_h;
+      for (int n = lo; n <= hi; ++n) {
+        int sh = (lv.H + n - 1) / n; sh += sh & 1;
+        const int nn = (lv.H + sh - 1) / sh;
+        const int64_t cost = ((nn * per_seg + 511) / 512) * (int64_t)(sh + 21);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_n = nn; best_h = sh; }
+      }
+      lv.n_seg = best_n; lv.seg_h = best_h;
+    }
   }
   // ---- workspace plan (float offsets)
   size_t off = 0;

@@ -1175,7 +1175,9 @@ def test_fused_band_kernels_write_the_heat_map_bands(W, H, F, fps, disp, mode):
         assert (m.fused_levels >= 1) == (fuse_mode == 1)
         runs[name] = (float(jod), st["Q_per_ch"], st["heatmap"].clone())
     assert abs(runs["split"][0] - runs["one_wave"][0]) < 2e-6
-    np.testing.assert_allclose(runs["split"][1], runs["one_wave"][1], rtol=3e-7, atol=0)
+    # (two separately compiled kernel families -- since round 5 the border strips too: k_band4s' EDGE body against k_band4f<4, 1> -- whose
+    # fp32 partial sums differ in the last bits: observed 6.7e-7)
+    np.testing.assert_allclose(runs["split"][1], runs["one_wave"][1], rtol=1.5e-6, atol=0)
     dl = (runs["split"][2].float() - runs["one_wave"][2].float()).abs()
     assert float(dl.max()) <= 1e-3 and float((dl > 0).float().mean()) < 1e-3      # (fp16 codes; the last-bit caveat of the test above)
     assert abs(runs["split"][0] - runs["unfused"][0]) < 1e-4

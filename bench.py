@@ -387,6 +387,7 @@ def main():
     ap.add_argument("--gen", default=None, choices=["cpu", "gpu"], help="frame generator (default: cpu when a reference fixture exists for the clip)")
     ap.add_argument("--frames", type=int, default=None, help="override the workload's frame count (per GPU or total)")
     ap.add_argument("--block-frames", type=int, default=None)
+    ap.add_argument("--score-frames", type=int, default=None, help="heat-map clips resident in HBM: frames per band / heat-map piece of a long temporal block (default: the metric's, 16)")
     ap.add_argument("--fps", type=int, default=None, help="override the workload's frame rate (e.g. 120: 31-tap temporal filters, k_fir_fused)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU baseline sample: a prefix of the workload clip (SURVEY 8d: 16; 0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
@@ -444,6 +445,8 @@ def main():
     scaling = "weak" if per_gpu_frames else "strong"
     first, count = plan_frame_shard(n_total, rank, world)
     m = cv.cvvdp(display_name=display, device=device, block_frames=args.block_frames, heatmap=heat)
+    if args.score_frames is not None:
+        m.score_frames = args.score_frames
     fl = int(np.ceil(0.250 * fps / 2) * 2) + 1   # cvvdp_metric.py:1059
     lo = max(0, first - (fl - 1))
     golden = None

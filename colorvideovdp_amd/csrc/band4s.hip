@@ -20,6 +20,12 @@
 // bit-identical and their partial sums agree to the last bit -- they are two separately compiled kernels, and the compiler contracts a
 // multiply-add here and not there (tests/test_gpu_parity.py::test_split_band_kernel_matches_the_one_wave_layout).  Only the strips away from the
 // image's left / right border run here (EDGE = 0 of band4f.hip); the border strips keep k_band4f<4, 1 / 2> on the edge stream.
+// BARRIERS IN DIVERGENT ROLES.  Front and back waves take different branches of `if (front)` and each runs its own copy of the
+// row loop; they meet at s_barrier, which counts arriving WAVES of the workgroup, not program points -- outside what the HIP model
+// promises for __syncthreads, and relied on deliberately.  What keeps it sound: both roles execute exactly two barriers per row step and
+// the same number of steps (prologue 2, real rows r_start .. rreal-1, reflected rows rreal .. rend-1, +1 under HEAT), every loop bound is
+// wave-uniform and the same expression in both roles, and tests/test_band4_isa.py checks on the generated code that every loop holding
+// barriers holds two per row step.  A wave that left early (the `wu >= ...` return) left as a whole workgroup.
 // Reference arithmetic: lpyr_dec.py:186-239,386-408, cvvdp_metric.py:835-856,945-950,963-971 (see band4.hip / band4f.hip).
 #include <type_traits>
 #include <utility>

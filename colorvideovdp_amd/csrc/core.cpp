@@ -520,7 +520,8 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     for (int l = 0; seg_rule && c.fuse_mode != 1 && l < h->fuse_levels; ++l) {
       Level& lv = h->lv[l];
       const int64_t per_seg = (int64_t)lv.n_strip * nominal * c.batch;
-      const int lo = (lv.H + 383) / 384, hi = std::max(lo, (lv.H + 47) / 48);      // (segments of at least 48 rows: 21 of them are overhead)
+      static const int fused_rows = dev_knob("CVVDP_FUSED_SEG_ROWS", 384);
+      const int lo = (lv.H + fused_rows - 1) / fused_rows, hi = std::max(lo, (lv.H + 47) / 48);      // (segments of at least 48 rows: 21 of them are overhead)
       int64_t best_cost = -1; int best_n = lv.n_seg, best_h = lv.seg_h;
       for (int n = lo; n <= hi; ++n) {
         int sh = (lv.H + n - 1) / n; sh += sh & 1;

@@ -84,6 +84,26 @@ def test_front_back_wave_kernels_are_safe_and_fit_four_waves_per_simd(tmp_path):
         body = "\n".join(text[s:e])
         assert body.count("s_waitcnt vmcnt(8)") >= 8 and (feat or body.count("s_waitcnt vmcnt(6)") >= 6)
         assert "scratch_" not in body or not ("_ZN5cvvdp8k_band4sE" in text[s])          # the plain kernel does not spill
+        # front and back waves run their own copies of the row loop and meet at s_barrier, which counts arrivals -- both roles must
+        # execute the same number of barriers per row.  On the generated code: every loop that holds barriers holds exactly two per row
+        # it advances -- the front's unrolled ring (8 rows: 16; the border body's 6 rows: 12), the back's even / odd row pair (4), and the
+        # one-row loops of the reflected rows below the image in either role (2).
+        body_lines = text[s:e]
+        labels = {l.split(":")[0]: i for i, l in enumerate(body_lines) if re.match(r"^\.LBB\d+_\d+:", l)}
+        n_front = 0
+        for i, l in enumerate(body_lines):
+            mm = re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
+            if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
+                loop = [x.split(";")[0].strip() for x in body_lines[labels[mm.group(1)]:i + 1]]
+                nb = sum(1 for x in loop if x.startswith("s_barrier"))
+                if not nb:
+                    continue
+                assert nb in (2, 4, 12, 16), (text[s].split(":")[0], nb)
+                steps = sum(1 for x in loop if re.match(r"s_waitcnt vmcnt\((8|6)\)$", x))      # the front's one wait per row step
+                if any(x.startswith("global_load_dwordx4") for x in loop):
+                    assert nb == 2 * steps and steps in (6, 8), (text[s].split(":")[0], nb, steps)
+                    n_front += 1
+        assert n_front == (1 if feat else 2)
     vg = [int(v) for v in re.findall(r"\.vgpr_count:\s+(\d+)", raw)]
     assert len(vg) == 3 and max(vg) <= 128, vg
     assert chk.check_file(str(asm)) == 0

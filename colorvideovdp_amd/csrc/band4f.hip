@@ -746,28 +746,15 @@ static int band4f_right_edge_strips(int W, int n_strip) {
   return n;
 }
 
-// whether launch_band4f puts a second launch (the border strips) on s_edge: not when k_band4s takes every strip itself
-#ifdef F_DIAG_OLD_EDGE      // A/B: round 4's route (the border strips on k_band4f<4, 1> beside k_band4s)
-bool band4f_uses_edge_stream(int, bool, bool) { return true; }
-#else
-bool band4f_uses_edge_stream(int W, bool one_wave_layout, bool features) { return one_wave_layout || (W & 3) != 0 || features; }
-#endif
-
 void launch_band4f(const BandArgs& a0, hipStream_t s, hipStream_t s_edge) {
   BandArgs a = a0;
-  if (!band4f_uses_edge_stream(a.W, a.one_wave_layout != 0, a.fsum != nullptr)) {
-    // front / back waves on every strip, the border strips included (band4s.hip EDGE): one launch, nothing on the edge stream
-    a.strip0 = 0; a.n_strip_l = a.n_strip; a.edge_in_s = 1;
-    a.per_xcd = (a.n_strip_l * a.n_seg * a.items + 7) / 8;
-    launch_band4s(a, s);
-    return;
-  }
-  a.edge_in_s = 0;
   const int n_edge = std::min(a.n_strip, 1 + band4f_right_edge_strips(a.W, a.n_strip));   // strip 0 + the right-edge strips
   a.strip0 = 0; a.n_strip_l = n_edge;
   a.per_xcd = (a.n_strip_l * a.n_seg * a.items + 7) / 8;
   const bool heat = a.dchr != nullptr, feat = a.fsum != nullptr;
-  if (feat) {
+  // the border strips: front / back waves too (band4s.hip EDGE) where that body exists -- W % 4 == 0, not the features clips
+  if (!feat && !a.one_wave_layout && (a.W & 3) == 0) launch_band4s_edge(a, s_edge);
+  else if (feat) {
     if ((a.W & 3) == 0) hipLaunchKernelGGL((k_band4f_feat<4, 1>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);
     else hipLaunchKernelGGL((k_band4f_feat<4, 2>), dim3(8 * a.per_xcd), dim3(256), 0, s_edge, a);
   } else if (heat) {
@@ -791,9 +778,6 @@ int tu_flags_band4f() {
   int f = 0;
 #ifdef CVVDP_SAFE_LOADS
   f |= CVVDP_BUILD_SAFE_LOADS;
-#endif
-#ifdef F_DIAG_OLD_EDGE
-  f |= CVVDP_BUILD_DIAG;
 #endif
   return f;
 }

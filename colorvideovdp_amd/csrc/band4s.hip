@@ -775,33 +775,34 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a, S4Lds<HEAT, FEAT>
 #endif
 }
 
-// One launch per level: every strip of the level, the work units dealt to the launch indices so that the blocks resident on one XCD are
-// neighbouring strips of the same rows (band4.hip).  Strips at the image's left / right border take the EDGE instantiation of the body
-// (a block-uniform branch), all others the border-free one.  W % 4 == 2 frames keep band4f.hip's partial-lane kernel for their border strips
-// (launch_band4f: a.edge_in_s == 0, strips strip0 .. strip0 + n_strip_l - 1 are then all border-free).
-template <bool HEAT, bool FEAT>
+// The strips of a fused level: the border-free ones (strips strip0 .. strip0 + n_strip_l - 1, launch_band4f) on k_band4s / _heat / _feat, the
+// ones at the image's left / right border (strip 0 and the last n_strip_l - 1) on k_band4s_edge / _edge_heat -- the EDGE body as kernels of
+// their own, launched beside the others on the edge stream.  Both bodies in ONE kernel (a block-uniform branch; one launch per level) were
+// measured too: the kernel grows from 25 to 52 KB of code and level 0 of 4K x 64 takes 7.34-7.50 ms instead of 7.13 (1080p: 2.03
+// against 1.92) -- the instruction cache (profiles/r05_ab_edge_route.txt).  The work units of a launch are dealt to the launch indices
+// so that the blocks resident on one XCD are neighbouring strips of the same rows (band4.hip).
+template <bool HEAT, bool FEAT, bool EDGE>
 __device__ __forceinline__ void band4s_kernel(const BandArgs& a) {
   __shared__ S4Lds<HEAT, FEAT> lds;
   const int per_xcd = a.per_xcd;
   const int wu = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);      // XCD-aware work-unit order (band4.hip)
   if (wu >= a.n_strip_l * a.n_seg * a.items) return;
   const int sl = wu % a.n_strip_l, seg = (wu / a.n_strip_l) % a.n_seg, item = wu / (a.n_strip_l * a.n_seg);
-  const int strip = a.strip0 + sl;
-#ifdef S_DIAG_EDGE_OFF      // timing only: the border strips on the border-free body (their results are wrong)
-  const bool edge = false;
-#else
-  const bool edge = !FEAT && a.edge_in_s && (strip == 0 || strip * S_SW + S_SW + S_HALO > a.W);
-#endif
-  // (FEAT: the back waves' 16 sum registers leave no room for the border code -- both bodies in one kernel spill the front's ring; features
-  // clips keep k_band4f_feat<4, 1> for their border strips, launch_band4f)
-  if constexpr (!FEAT) {
-    if (edge) { band4s_body<HEAT, FEAT, true>(a, lds, strip, seg, item); return; }
-  }
-  band4s_body<HEAT, FEAT, false>(a, lds, strip, seg, item);
+  const int strip = EDGE ? (sl == 0 ? 0 : a.n_strip - a.n_strip_l + sl) : a.strip0 + sl;
+  band4s_body<HEAT, FEAT, EDGE>(a, lds, strip, seg, item);
 }
-__global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) { band4s_kernel<false, false>(a); }
-__global__ __launch_bounds__(512, 4) void k_band4s_heat(BandArgs a) { band4s_kernel<true, false>(a); }
-__global__ __launch_bounds__(512, 4) void k_band4s_feat(BandArgs a) { band4s_kernel<false, true>(a); }
+__global__ __launch_bounds__(512, 4) void k_band4s(BandArgs a) { band4s_kernel<false, false, false>(a); }
+__global__ __launch_bounds__(512, 4) void k_band4s_heat(BandArgs a) { band4s_kernel<true, false, false>(a); }
+__global__ __launch_bounds__(512, 4) void k_band4s_feat(BandArgs a) { band4s_kernel<false, true, false>(a); }
+// (no _edge_feat: the back waves' 16 sum registers leave no room for the border code; features clips keep k_band4f_feat<4, 1> for their
+// border strips, launch_band4f)
+__global__ __launch_bounds__(512, 4) void k_band4s_edge(BandArgs a) { band4s_kernel<false, false, true>(a); }
+__global__ __launch_bounds__(512, 4) void k_band4s_edge_heat(BandArgs a) { band4s_kernel<true, false, true>(a); }
+
+void launch_band4s_edge(const BandArgs& a, hipStream_t s) {
+  if (a.dchr) hipLaunchKernelGGL(k_band4s_edge_heat, dim3(8 * a.per_xcd), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL(k_band4s_edge, dim3(8 * a.per_xcd), dim3(512), 0, s, a);
+}
 
 void launch_band4s(const BandArgs& a, hipStream_t s) {
   if (a.fsum) hipLaunchKernelGGL(k_band4s_feat, dim3(8 * a.per_xcd), dim3(512), 0, s, a);
@@ -815,7 +816,7 @@ int tu_flags_band4s() {
   f |= CVVDP_BUILD_SAFE_LOADS;
 #endif
 #if defined(S_DIAG_NOBAR) || defined(S_DIAG_BACK_ONLY) || defined(S_DIAG_FRONT_ONLY) || defined(S_DIAG_NO_STORE) || defined(S_DIAG_PLAIN_STORE) || \
-    defined(S_DIAG_NO_NB) || defined(S_DIAG_NO_SG) || defined(S_DIAG_EDGE_OFF) || defined(S_DIAG_EDGE_RING) || defined(S_DIAG_NO_LUM) || defined(S_PRIO_FRONT) || defined(S_PRIO_BACK) || CVVDP_BAND4S_RING != 8
+    defined(S_DIAG_NO_NB) || defined(S_DIAG_NO_SG) || defined(S_DIAG_EDGE_RING) || defined(S_DIAG_NO_LUM) || defined(S_PRIO_FRONT) || defined(S_PRIO_BACK) || CVVDP_BAND4S_RING != 8
   f |= CVVDP_BUILD_DIAG;
 #endif
   return f;

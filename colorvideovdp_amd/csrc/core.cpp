@@ -280,7 +280,7 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
       launch_heat_init(a.hstats, items, s);
       h->last_range_done = true;
     }
-    if ((fused && band4f_uses_edge_stream(lv.W, h->c.band_layout == 1, lv.feat4)) || (!fused && lv.vec4 && lv.split_edge)) {
+    if (fused || (lv.vec4 && lv.split_edge)) {
       if (!h->edge_stream) {
         if (hipStreamCreateWithFlags(&h->edge_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_edge_fork, hipEventDisableTiming) != hipSuccess ||

@@ -180,7 +180,6 @@ struct BandArgs {
   // k_band4f (band4f.hip): the level's reduce fused in -- level l+1 planes [2*nch][items_cap][Hc*Wc] written by the band kernel, reduce taps
   float* g1_out;
   float rk[5];
-  int32_t edge_in_s;         // launch_band4f -> k_band4s: the launch holds ALL strips, the ones at the image border on the EDGE instantiation of the body (W % 4 == 0)
   int32_t one_wave_layout;   // launch_band4f: the border-free strips on k_band4f<4, 0> (one wave per channel) instead of k_band4s (front / back waves)
 };
 void launch_band(const BandArgs& a, bool blur, hipStream_t s);
@@ -195,9 +194,10 @@ int band4_edge_strips(int W, int n_strip);   // how many trailing strips the RAG
 bool band4f_supported(int H, int W);
 // (the strips at the left / right image border as their own launch on s_edge -- a side stream ordered like launch_band4's, or s)
 void launch_band4f(const BandArgs& a, hipStream_t s, hipStream_t s_edge);
-bool band4f_uses_edge_stream(int W, bool one_wave_layout, bool features);   // false: one launch on s (k_band4s with the border strips on its EDGE body)
 // band4s.hip: the border-free strips of a fused level (a.strip0 .. a.strip0 + a.n_strip_l - 1) with the work divided between front and back waves
 void launch_band4s(const BandArgs& a, hipStream_t s);
+// ... and its border strips (strip 0 and the last a.n_strip_l - 1; W % 4 == 0, plain or heat map) on the same layout's EDGE body
+void launch_band4s_edge(const BandArgs& a, hipStream_t s);
 constexpr int kBand4StripWidth = 240;
 // How each band translation unit was compiled, for cvvdp_build_flags(): CVVDP_BUILD_SAFE_LOADS (-DCVVDP_SAFE_LOADS) and CVVDP_BUILD_DIAG
 // (a timing-only switch or a non-default ring / load-hint macro: results wrong or not the product's).  0 for the product build.

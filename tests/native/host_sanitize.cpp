@@ -147,13 +147,11 @@ void launch_band4(const BandArgs& a, bool split_edge, hipStream_t s, hipStream_t
   else REQUIRE(s == s_edge, "k_band4: side stream without a split");
 }
 bool band4f_supported(int H, int W) { return (W & 1) == 0 && W >= 32 && H >= 32; }   // (mirror of band4f.hip)
-bool band4f_uses_edge_stream(int W, bool one_wave_layout, bool features) { return one_wave_layout || (W & 3) != 0 || features; }   // (mirror of band4f.hip)
 int tu_flags_band4() { return 0; }
 int tu_flags_band4f() { return 0; }
 int tu_flags_band4s() { return 0; }
-void launch_band4f(const BandArgs& a, hipStream_t s, hipStream_t s_edge) {
+void launch_band4f(const BandArgs& a, hipStream_t, hipStream_t) {
   chk_band(a, kBand4StripWidth, "k_band4f");
-  REQUIRE(band4f_uses_edge_stream(a.W, a.one_wave_layout != 0, a.fsum != nullptr) || s == s_edge, "k_band4f: side stream for a level whose strips all run in one launch (%d wide)", a.W);
   REQUIRE(band4f_supported(a.H, a.W) && a.nch == 4 && a.seg_h % 2 == 0 && a.seg_h >= 8, "k_band4f on %dx%d, %d channels, seg_h %d", a.W, a.H, a.nch, a.seg_h);
   REQUIRE(!a.ddump && !a.fdump && !(a.dchr && a.fsum), "k_band4f with a dump / per-pixel feature buffer");       // (heat-map band / column sums: the HEAT / FEAT instantiations)
   in_ws(a.g1_out, 2 * (size_t)a.nch * a.items_cap_c * a.Hc * a.Wc, "k_band4f level l+1 planes");

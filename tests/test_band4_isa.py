@@ -59,7 +59,7 @@ def test_fused_kernel_streams_are_safe_too(tmp_path):
 @pytest.mark.skipif(not os.path.exists(HIPCC) and shutil.which("hipcc") is None, reason="hipcc not available")
 def test_front_back_wave_kernels_are_safe_and_fit_four_waves_per_simd(tmp_path):
     """k_band4s / k_band4s_heat / k_band4s_feat (band4s.hip): the front waves' 8-row ring with six loads per step and ONE wait per step
-    (vmcnt(8); the border-strip body of the plain / heat kernels: a 6-row ring and vmcnt(6)); 128 VGPRs at most, or the two 8-wave blocks per CU (four waves per SIMD) the layout exists for do not fit; the
+    (vmcnt(8); the border-strip kernels k_band4s_edge / _edge_heat: a 6-row ring and vmcnt(6)); 128 VGPRs at most, or the two 8-wave blocks per CU (four waves per SIMD) the layout exists for do not fit; the
     k_band4f_heat / _feat instantiations must hold no hand-issued load at all (compiler-managed: they spill)."""
     import re
     spec = importlib.util.spec_from_file_location("check_band4_isa", os.path.join(ROOT, "tools", "check_band4_isa.py"))
@@ -72,18 +72,20 @@ def test_front_back_wave_kernels_are_safe_and_fit_four_waves_per_simd(tmp_path):
     assert p.returncode == 0, p.stderr[-2000:]
     raw = asm.read_text()
     text = raw.split("\n")
-    starts = [i for i, l in enumerate(text) if re.match(r"^_ZN5cvvdp\d+k_band4s(_heat|_feat)?E.*:\s*(;.*)?$", l)]
-    assert len(starts) == 3
+    starts = [i for i, l in enumerate(text) if re.match(r"^_ZN5cvvdp\d+k_band4s(_edge)?(_heat|_feat)?E.*:\s*(;.*)?$", l)]
+    assert len(starts) == 5
     for s in starts:
         e = next(i for i in range(s, len(text)) if ".end_amdhsa_kernel" in text[i] or text[i].startswith("\t.section"))
         bad, n_loads, n_loops = chk.check_kernel(text[s].split(":")[0], text[s:e])
-        # eight steps x (four neighbour loads + two row loads) of the border-free body; plain and heat kernels also hold the border-strip
-        # body (round 5: EDGE, a ring of six rows): six more steps of six loads, one vmcnt(6) each
-        feat = "_feat" in text[s].split(":")[0]
-        assert n_loads == (48 if feat else 48 + 36) and bad == 0, (text[s], n_loads, bad)
+        # eight steps x (four neighbour loads + two row loads) in the border-free kernels, one vmcnt(8) per step; the border-strip kernels
+        # (round 5: k_band4s_edge / _edge_heat, a ring of six rows): six steps of six loads, one vmcnt(6) each
+        kname = text[s].split(":")[0]
+        edge = "_edge" in kname
+        feat = "_feat" in kname
+        assert n_loads == (36 if edge else 48) and bad == 0, (text[s], n_loads, bad)
         body = "\n".join(text[s:e])
-        assert body.count("s_waitcnt vmcnt(8)") >= 8 and (feat or body.count("s_waitcnt vmcnt(6)") >= 6)
-        assert "scratch_" not in body or not ("_ZN5cvvdp8k_band4sE" in text[s])          # the plain kernel does not spill
+        assert body.count("s_waitcnt vmcnt(6)") >= 6 if edge else body.count("s_waitcnt vmcnt(8)") >= 8
+        assert "scratch_" not in body or kname not in ("_ZN5cvvdp8k_band4sENS_8BandArgsE", "_ZN5cvvdp13k_band4s_edgeENS_8BandArgsE")   # the plain kernels do not spill
         # front and back waves run their own copies of the row loop and meet at s_barrier, which counts arrivals -- both roles must
         # execute the same number of barriers per row.  On the generated code: every loop that holds barriers holds exactly two per row
         # it advances -- the front's unrolled ring (8 rows: 16; the border body's 6 rows: 12), the back's even / odd row pair (4), and the
@@ -103,7 +105,7 @@ def test_front_back_wave_kernels_are_safe_and_fit_four_waves_per_simd(tmp_path):
                 if any(x.startswith("global_load_dwordx4") for x in loop):
                     assert nb == 2 * steps and steps in (6, 8), (text[s].split(":")[0], nb, steps)
                     n_front += 1
-        assert n_front == (1 if feat else 2)
+        assert n_front == 1
     vg = [int(v) for v in re.findall(r"\.vgpr_count:\s+(\d+)", raw)]
-    assert len(vg) == 3 and max(vg) <= 128, vg
+    assert len(vg) == 5 and max(vg) <= 128, vg
     assert chk.check_file(str(asm)) == 0

@@ -99,7 +99,7 @@ def main(paths):
 
 def check_file(path):
     text = open(path).read().split("\n")
-    starts = [i for i, l in enumerate(text) if re.match(r"^_ZN5cvvdp\d+k_band4[fs]?(_heat|_feat)?[IE].*:\s*(;.*)?$", l)]
+    starts = [i for i, l in enumerate(text) if re.match(r"^_ZN5cvvdp\d+k_band4[fs]?(_edge)?(_heat|_feat)?[IE].*:\s*(;.*)?$", l)]
     total_bad = 0
     for s in starts:
         e = next(i for i in range(s, len(text)) if ".end_amdhsa_kernel" in text[i] or text[i].startswith("\t.section"))

@@ -3,7 +3,7 @@
 # kernel trace, HBM traffic counters (separate --pmc passes), SQ counters, the stamp of the sources they were measured on, and the
 # default bench line from the same box.    tools/refresh_counters.sh r03   -> gpurun_out/refresh/<tag>_*
 set -u
-TAG=${1:-r03}
+TAG=${1:-r05}
 R=$(pwd)
 OUT=$R/gpurun_out/refresh
 mkdir -p $OUT
@@ -20,5 +20,5 @@ rm -rf $OUT/kt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 python -c "import bench, json; print(json.dumps(bench.code_stamp()))" > $OUT/${TAG}_stamp.json
 tools/sq_counters.sh > $OUT/${TAG}_pmc_sq_counters_body.txt 2> $OUT/sq.err
 timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
-grep -E "k_band4s\(|k_band4f<4, 1>" $OUT/${TAG}_kernel_trace.txt | grep -E " (5376|768) " | tail -2
+grep -E "k_band4s\(" $OUT/${TAG}_kernel_trace.txt | grep -E " 6144 " | tail -2
 cat $OUT/${TAG}_bench.json | cut -c1-400

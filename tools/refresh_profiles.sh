@@ -4,7 +4,7 @@
 # Writes everything under gpurun_out/refresh/ (merged back by gpurun); copy the *.txt/*.json into profiles/ and run
 # tools/make_traffic_json.py <tag>.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$(pwd)
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT

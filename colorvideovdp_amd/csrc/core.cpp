@@ -212,7 +212,12 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
   // keep the single stream: measured on 4K x 64, the overlap gains 0.1 ms of 19 and only makes the per-kernel timings overlap.
   static const bool fork_env = dev_knob("CVVDP_BAND_STREAMS", 1) != 0;
   static const int fork_max = dev_knob("CVVDP_BAND_STREAMS_MAX", 1024);
-  bool fork = !fused && fork_env && L >= 4 && (int64_t)items * h->lv[0].n_strip * h->lv[0].n_seg <= fork_max;
+  // Round 5: the same for the levels BEHIND the fused ones of a large block (4K x 64: levels 3.., 1080p: levels 2..): each is at most one
+  // round of workgroups, they depend on the reduce chain only, and one after the other their launches leave the GPU half empty between
+  // them -- so the rule looks at the first level this call runs, not at level 0.
+  static const int fork_tail = dev_knob("CVVDP_BAND_STREAMS_TAIL", 1);
+  const int l_size = (fork_tail && !fused) ? std::min(l_begin, L - 1) : 0;
+  bool fork = !fused && fork_env && L - l_size >= 4 && (int64_t)items * h->lv[l_size].n_strip * h->lv[l_size].n_seg <= fork_max;
   if (fork && !h->aux_stream[0]) {
     bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i)
@@ -227,7 +232,7 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
   hipStream_t const s_main = s;
   for (int l = l_begin; l < l_end; ++l) {
     const Level& lv = h->lv[l];
-    hipStream_t s = (fork && l >= 2) ? h->aux_stream[l & 1] : s_main;
+    hipStream_t s = (fork && l >= l_size + 2) ? h->aux_stream[l & 1] : s_main;      // (the first two levels of the call stay on the caller's stream)
     ProfScope ps(h, l == 0 ? CVVDP_PROF_BAND0 : CVVDP_PROF_BAND_REST, s);
     BandArgs a{};
     a.g = gbase(h, l, set) + (l == 0 ? (size_t)item0 * h->lv[0].P : 0);

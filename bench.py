@@ -576,7 +576,7 @@ def main():
                 traffic_note = ("FETCH_SIZE x 2 + WRITE_SIZE per launch from separate --pmc passes over these kernel sources (stamp matches; "
                                 f"library binary {'identical' if have.get('lib_sha256') == stamp['lib_sha256'] else 'rebuilt from the same sources'})")
         out["roofline"] = {"bound": "hbm", "kernel": ("k_band4s level 0 (front waves: ring, 5x5 reduce to level 1, expand, luminance terms; back waves: contrast, CSF, masking, "
-                                                      "blurs, pooling), one launch for every strip of the level -- the strips at the image border on the kernel's EDGE body") if fused_levels > 0 else
+                                                      "blurs, pooling) + k_band4s_edge (the same layout's EDGE body) on the border strips as a second launch beside it: the pair is timed") if fused_levels > 0 else
                                                      "k_band4<4> level 0 (fused expand/contrast/CSF/masking/blur/pooling)",
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                            "traffic": traffic, "traffic_note": traffic_note, "avg_launch_ms": round(avg_ms, 4), "launches": n,

@@ -101,7 +101,7 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
   const int x0 = strip * F_SW;
   const int fc0 = x0 - F_HALO + 4 * j;
   const bool in_img = fc0 >= 0 && fc0 < W;
-  const bool edge_r = x0 + F_SW + F_HALO > W;
+  const bool edge_r = x0 + F_SW + F_HALO >= W;     // (>=: a strip whose LAST lane holds columns W-4 .. W-1 computes the last coarse column, band4f_right_edge_strips)
   constexpr bool edge_lr = EDGE != 0;               // (launch_band4f deals the strips accordingly)
   const bool part = RAG && in_img && fc0 + 4 > W;   // the partial lane (fc0 == W - 2)
   const bool interior = j >= 2 && j < 62 && fc0 < W;
@@ -739,10 +739,13 @@ __global__ __launch_bounds__(64 * NCH, 2) void k_band4f_feat(BandArgs a) { band4
 
 bool band4f_supported(int H, int W) { return (W & 1) == 0 && W >= 32 && H >= 32; }
 
-// strips whose 256 columns x0-8 .. x0+247 reach past the right image border (trailing; at least the last one)
+// strips whose 256 columns x0-8 .. x0+247 reach the right image border (trailing; at least the last one).  Reaching column W-1 is
+// enough (round 5: >=, it was >): the lane of columns W-4 .. W-1 computes the LAST coarse column, whose extra taps (lpyr_dec.py:205-209)
+// and zero right neighbour only the border body applies -- and when that lane is a strip's lane 63 (W = 240 k + 248: 488, 728, 968, ..),
+// its coarse column still feeds the expand of columns W-4, W-3, which the blur of the strip's last interior columns reads.
 static int band4f_right_edge_strips(int W, int n_strip) {
   int n = 0;
-  while (n < n_strip && (n_strip - 1 - n) * F_SW + F_SW + F_HALO > W) ++n;
+  while (n < n_strip && (n_strip - 1 - n) * F_SW + F_SW + F_HALO >= W) ++n;
   return n;
 }
 

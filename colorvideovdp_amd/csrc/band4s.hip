@@ -115,7 +115,7 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a, S4Lds<HEAT, FEAT>
   const int x0 = strip * S_SW;
   const int fc0 = x0 - S_HALO + 4 * j;
   const bool in_img = !EDGE || (fc0 >= 0 && fc0 < W);
-  const bool edge_r = EDGE && x0 + S_SW + S_HALO > W;
+  const bool edge_r = EDGE && x0 + S_SW + S_HALO >= W;      // (the strip reaches column W-1: band4f.hip band4f_right_edge_strips)
   const bool interior = j >= 2 && j < 62 && (!EDGE || fc0 < W);
   const int cb = (x0 - S_HALO) / 2;
   const int ys = seg * a.seg_h, ye = min(H, ys + a.seg_h);

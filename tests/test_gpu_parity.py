@@ -948,6 +948,7 @@ def _fuse_clip(W, H, F, seed):
     (512, 271, 4, 24, "standard_fhd"),        # odd height: the last coarse row's extra taps, the row-parity column edge (Q1)
     (1200, 90, 3, 50, "standard_4k"),         # W a multiple of the strip width, few rows: top and bottom mirrors in one segment
     (248, 600, 3, 60, "standard_hdr_pq"),     # a strip whose 256 columns end exactly at the image; tall
+    (728, 120, 3, 60, "standard_fhd"),        # ... and not the first strip: lane 63 of strip 2 computes the LAST coarse column (round 5: a border strip)
     (152, 69, 12, 30, "standard_fhd"),        # segments of 14 rows: shorter than two blur radii, the last one 13 rows
     # W % 8 != 0 (even widths): the border strips' instantiation with a partial lane (W % 4 == 2) / the aligned one at W % 8 == 4
     (1366, 200, 3, 60, "standard_4k"),        # the laptop width: six strips, level 0 fused (683 columns at level 1: odd, reduce pass)
@@ -1041,6 +1042,7 @@ def test_fused_route_is_a_property_of_the_clip():
     (736, 416, 5, 30, "standard_fhd"),        # four strips (the last one 16 columns), several row segments, odd frame count
     (1446, 333, 2, 60, "standard_hdr_pq"),    # W % 4 == 2 (partial-lane border kernel beside the split kernel), odd height
     (3840, 270, 2, 60, "standard_4k"),        # the bench clip's width: 14 of 16 strips on the split kernel
+    (728, 96, 2, 30, "standard_fhd"),         # strip 2 ends exactly at the image: a border strip in both layouts
 ])
 def test_split_band_kernel_matches_the_one_wave_layout(W, H, F, fps, disp):
     import colorvideovdp_amd as cv
@@ -1162,6 +1164,7 @@ def test_device_heatmap_sink_gets_the_same_frames_without_pcie():
     # edge-stream kernel's atomics, which must be ordered after the initialisation of the range words on the main stream
     (472, 240, 3, 60, "standard_fhd", "threshold"),            # two strips, both at the border
     (232, 176, 2, 60, "standard_fhd", "supra-threshold"),      # one strip with both borders
+    (488, 150, 2, 60, "standard_fhd", "raw"),                  # W = 240 + 248: strip 1 ends exactly at the image (its lane 63 = the last coarse column)
 ])
 def test_fused_band_kernels_write_the_heat_map_bands(W, H, F, fps, disp, mode):
     import colorvideovdp_amd as cv

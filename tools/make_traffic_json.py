@@ -16,9 +16,10 @@ PIX = 3840 * 2160 * 64
 KERNELS = {
     # key: (substrings of the kernel names whose largest launches are ADDED, algorithmic bytes per step, what they are)
     "temporal_fir": (["k_fir_rot<3, 17>"], PIX * (24 + 32.0), "24 B/pixel in (fp32 RGB, test + reference) + 32 B/pixel out (8 level-0 planes)"),
-    "band_level0": (["k_band4s("], PIX * 40.0,
-                    "k_band4s, one launch for every strip of level 0 (round 5: the border strips on its EDGE body): g0 (32 B/pixel) in, g1 (8 B/pixel) out"),
-    "band_level1": (["k_band4s(#2"], PIX * 10.0, "the same kernel at level 1: g1 in, g2 out"),
+    "band_level0": (["k_band4s(", "k_band4s_edge("], PIX * 40.0,
+                    "k_band4s + k_band4s_edge: g0 (32 B/pixel) in, g1 (8 B/pixel) out; two launches side by side (strips inside the image; strips at "
+                    "its left and right border on the same front / back-wave layout's EDGE body, round 5)"),
+    "band_level1": (["k_band4s(#2", "k_band4s_edge(#2"], PIX * 10.0, "the same pair at level 1: g1 in, g2 out"),
 }
 
 

@@ -12,6 +12,6 @@ BENCH="python bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-profile --gen gp
 python $R/tools/rocpd_summary.py "$(find $OUT/kt -name '*.db' | head -1)" > $OUT/${TAG}_kernel_trace.txt
 rm -rf $OUT/kt
 timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
-grep -E "k_band4s\(" $OUT/${TAG}_kernel_trace.txt | grep -E " 6144 " | tail -2
+grep -E "k_band4s(_edge)?\(" $OUT/${TAG}_kernel_trace.txt | grep -E " (5376|768) " | tail -2
 python -c "
 import json; d=json.loads(open('$OUT/${TAG}_bench.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'])"

@@ -20,5 +20,5 @@ rm -rf $OUT/kt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 python -c "import bench, json; print(json.dumps(bench.code_stamp()))" > $OUT/${TAG}_stamp.json
 tools/sq_counters.sh > $OUT/${TAG}_pmc_sq_counters_body.txt 2> $OUT/sq.err
 timeout 900 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
-grep -E "k_band4s\(" $OUT/${TAG}_kernel_trace.txt | grep -E " 6144 " | tail -2
+grep -E "k_band4s(_edge)?\(" $OUT/${TAG}_kernel_trace.txt | grep -E " (5376|768) " | tail -2
 cat $OUT/${TAG}_bench.json | cut -c1-400

@@ -11,5 +11,5 @@ for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
   i=$((i+1))
   ( cd $R && timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/sq$i -o sq$i -- python bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-profile > /tmp/sq$i.log 2>&1 )
   db=$(find /tmp/sq$i -name "*.db" | head -1)
-  python $R/tools/rocpd_summary.py $db | grep -A400 "PMC counters" | grep -E "k_band4s\(|k_band4f<4, (0|1)>|k_band4<4, false, false, false, false>|k_fir_rot<3, 17>|k_reduce2" | awk '$0 ~ / 5376 / || $0 ~ / 1152 / || $0 ~ / 768 / || $0 ~ / 384 / || $0 ~ / 6144 / || $0 ~ / 1536 / || $0 ~ / 512 / || $0 ~ / 64800 / || $0 ~ / 9216 /'
+  python $R/tools/rocpd_summary.py $db | grep -A400 "PMC counters" | grep -E "k_band4s\(|k_band4s_edge\(|k_band4f<4, (0|1)>|k_band4<4, false, false, false, false>|k_fir_rot<3, 17>|k_reduce2" | awk '$0 ~ / 5376 / || $0 ~ / 1152 / || $0 ~ / 768 / || $0 ~ / 384 / || $0 ~ / 256 / || $0 ~ / 6144 / || $0 ~ / 1536 / || $0 ~ / 512 / || $0 ~ / 64800 / || $0 ~ / 9216 /'
 done

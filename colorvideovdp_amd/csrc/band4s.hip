@@ -18,8 +18,10 @@
 //
 // The arithmetic is k_band4f<4, 0>'s, operation for operation (same FMA chains, same order): the two kernels' level-(l+1) planes are
 // bit-identical and their partial sums agree to the last bit -- they are two separately compiled kernels, and the compiler contracts a
-// multiply-add here and not there (tests/test_gpu_parity.py::test_split_band_kernel_matches_the_one_wave_layout).  Only the strips away from the
-// image's left / right border run here (EDGE = 0 of band4f.hip); the border strips keep k_band4f<4, 1 / 2> on the edge stream.
+// multiply-add here and not there (tests/test_gpu_parity.py::test_split_band_kernel_matches_the_one_wave_layout).  The strips away from the
+// image's left / right border run the EDGE = 0 body (k_band4s / _heat / _feat); since round 5 the border strips of W % 4 == 0 frames run
+// the same layout's EDGE = 1 body as kernels of their own (k_band4s_edge / _edge_heat, on the edge stream beside the others); W % 4 == 2
+// frames and features clips keep k_band4f<4, 2> / k_band4f_feat<4, 1> for their border strips (launch_band4f).
 // BARRIERS IN DIVERGENT ROLES.  Front and back waves take different branches of `if (front)` and each runs its own copy of the
 // row loop; they meet at s_barrier, which counts arriving WAVES of the workgroup, not program points -- outside what the HIP model
 // promises for __syncthreads, and relied on deliberately.  What keeps it sound: both roles execute exactly two barriers per row step and

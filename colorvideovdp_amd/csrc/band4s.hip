@@ -780,8 +780,10 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a, S4Lds<HEAT, FEAT>
 // The strips of a fused level: the border-free ones (strips strip0 .. strip0 + n_strip_l - 1, launch_band4f) on k_band4s / _heat / _feat, the
 // ones at the image's left / right border (strip 0 and the last n_strip_l - 1) on k_band4s_edge / _edge_heat -- the EDGE body as kernels of
 // their own, launched beside the others on the edge stream.  Both bodies in ONE kernel (a block-uniform branch; one launch per level) were
-// measured too: the kernel grows from 25 to 52 KB of code and level 0 of 4K x 64 takes 7.34-7.50 ms instead of 7.13 (1080p: 2.03
-// against 1.92) -- the instruction cache (profiles/r05_ab_edge_route.txt).  The work units of a launch are dealt to the launch indices
+// measured too: in the timed step level 0 of 4K x 64 takes 7.34-7.50 ms instead of 7.13 (1080p: 2.03 against 1.92).  Not the code size
+// (52 KB against 25 + 27): the instruction cache hits 99.9997 % of its requests either way, and run alone the two routes take the same
+// 460 M SQ busy cycles (profiles/r05_icache_counters.txt) -- two launches side by side pack onto the CUs better than one launch whose
+// slower border blocks are dealt among the others (profiles/r05_ab_edge_route.txt).  The work units of a launch are dealt to the launch indices
 // so that the blocks resident on one XCD are neighbouring strips of the same rows (band4.hip).
 template <bool HEAT, bool FEAT, bool EDGE>
 __device__ __forceinline__ void band4s_kernel(const BandArgs& a) {

@@ -6,7 +6,7 @@ VERDICT r4 weak #3: nothing beyond 64 frames at 8K had been held against the ref
 per-frame Q_per_ch of an 80-frame clip are the first 80 frames' of any longer clip: the GPU test scores the FULL 256-frame clip --
 several temporal blocks, the machinery configs[4] runs on -- and compares its first 80 frames with this fixture.
 Stored: Q_per_ch [1,4,80,9], rho_band, JOD of the 80-frame clip, checksums of the regenerated inputs.  Container only (imports
-/root/reference through oracle/ref_shims); about two hours on 8 cores; the frames are made on demand (a streamed video_source).
+/root/reference through oracle/ref_shims); 56 minutes on 8 cores; the frames are made on demand (a streamed video_source).
 
     python oracle/make_goldens_8k80.py
 """

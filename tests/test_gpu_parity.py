@@ -480,14 +480,19 @@ def test_configs2_at_full_length_in_fp32_against_reference():
 def test_configs4_clip_at_full_length_first_80_frames_against_reference():
     """configs[4]'s clip as bench.py makes it -- 7680x4320, PQ, uint8 codes in the PQ range -- scored at its FULL length of 256 frames
     (several temporal blocks at 8K; VERDICT r4 weak #3: nothing beyond 64 frames at 8K had met the reference).  The reference's scores
-    exist for the first 80 frames (oracle/make_goldens_8k80.py: two hours of its CPU path); the temporal filter is causal, so they are
+    exist for the first 80 frames (oracle/make_goldens_8k80.py: 56 minutes of its CPU path); the temporal filter is causal, so they are
     the first 80 frames' scores of the 256-frame clip."""
     import bench
     import colorvideovdp_amd as cv
     g = load_golden("deep_8k_pq_80f")
     W, H, Fg = int(g["width"]), int(g["height"]), int(g["frames"])
     F = 256
-    clip = bench.ResidentClip(F, 0, F, H, W, float(g["fps"]), "u8", torch.device("cuda"), gen="cpu", pq_range=True)
+    # the first 80 frames from the CPU generator the fixture was made with, the other 176 from the (much faster) device generator: what
+    # follows frame 79 cannot change the scores of frames 0..79
+    clip = bench.ResidentClip(F, 0, F, H, W, float(g["fps"]), "u8", torch.device("cuda"), gen="gpu", pq_range=True)
+    head = bench.ResidentClip(Fg, 0, Fg, H, W, float(g["fps"]), "u8", torch.device("cuda"), gen="cpu", pq_range=True)
+    clip.test[:, :, :Fg], clip.ref[:, :, :Fg] = head.test, head.ref
+    del head
     cs = (int(clip.test[:, :, :Fg].to(torch.int64).sum()), int(clip.ref[:, :, :Fg].to(torch.int64).sum()))
     if cs != (int(g["checksum_test"]), int(g["checksum_ref"])):
         pytest.fail("this torch build's CPU generator does not reproduce the fixture's synthetic frames (checksum mismatch)")

@@ -372,6 +372,12 @@ class cvvdp(vq_metric):
             nb = int(self.block_frames)
         else:
             free, _total = torch.cuda.mem_get_info(self.device)
+            # ... plus what torch's caching allocator holds without using it: this process gets those blocks back before the driver is
+            # asked (after a large clip the device looks full to mem_get_info while nearly all of it is cached and free)
+            try:
+                free += max(0, torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device))
+            except Exception:
+                pass
             budget = free * 0.55
             if self.gpu_mem is not None:
                 budget = min(budget, self.gpu_mem * 1e9)

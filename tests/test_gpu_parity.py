@@ -508,6 +508,8 @@ def test_configs4_clip_at_full_length_first_80_frames_against_reference():
     m2 = cv.cvvdp(display_name=str(g["display"]), block_frames=64)
     _, s2 = m2.predict_video_source(clip)
     np.testing.assert_array_equal(s2["Q_per_ch"], stats["Q_per_ch"])
+    del clip, m, m2
+    torch.cuda.empty_cache()
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -270,21 +270,30 @@ def device_identity(rank, dev_index):
             "host": os.uname().nodename}
 
 
-def measured_copy_ceiling():
-    """The best rate a float4 device copy (read + write) reached on a gpurun box: profiles/*ubench_hbm_copy_sweep.txt (tools/ubench/
-    hbm_copy_sweep.hip: plain / nontemporal accesses, 1-8 in flight, grid-stride / chunked, 1 024-16 384 blocks), the newest file.
-    The second denominator SURVEY 8(d) asks for: no read+write stream on these boxes gets closer to the 8 TB/s of the data sheet."""
+def measured_copy_ceiling(working_set_mb=None):
+    """The rate a float4 device copy (read + write) reaches on a gpurun box AT THE WORKING-SET SIZE of the step: the newest
+    profiles/*ubench_hbm_copy_size_shape.txt (tools/ubench/hbm_copy_size_shape.hip, section A: bytes per side -> TB/s for three access
+    patterns).  Copies whose two buffers fit the 256 MB Infinity Cache run at 6.3-7.2 TB/s; a pass over gigabytes -- what every kernel
+    of this path is -- gets 5.4-6.0.  The row at (or just above) `working_set_mb` per side is taken, the largest row when it is None or
+    beyond the sweep.  The second denominator SURVEY 8(d) asks for."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*ubench_hbm_copy_sweep.txt")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*ubench_hbm_copy_size_shape.txt")))
     if not files:
         return None
-    best = 0.0
+    rows = []
     for line in open(files[-1]):
-        mt = re.match(r"copy .*?([0-9.]+) TB/s", line)
+        mt = re.match(r"\s*(\d+) MB per side:(.*)", line)
         if mt:
-            best = max(best, float(mt.group(1)))
-    return {"GBs": best * 1e3, "source": "profiles/" + os.path.basename(files[-1]) + " (best float4 copy of the sweep)"} if best > 0 else None
+            rates = [float(x) for x in re.findall(r"([0-9.]+) TB/s", mt.group(2))]
+            if rates:
+                rows.append((int(mt.group(1)), max(rates)))
+    if not rows:
+        return None
+    rows.sort()
+    pick = next((r for r in rows if working_set_mb is not None and r[0] >= working_set_mb), rows[-1])
+    return {"GBs": pick[1] * 1e3, "MB_per_side": pick[0], "working_set_MB_per_side": None if working_set_mb is None else round(working_set_mb),
+            "source": "profiles/" + os.path.basename(files[-1]) + f" (best of the three float4 copies at {pick[0]} MB per side)"}
 
 
 def power_probe(step, sync, seconds=1.6):
@@ -369,6 +378,11 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def _capi_build_info():
+    from colorvideovdp_amd import _capi
+    return _capi.build_info()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -430,6 +444,10 @@ def main():
         # which device every rank really sits on (the SCALE record shows N distinct GPUs, or says that the ranks share one)
         ranks_seen = [None] * world
         torch.distributed.all_gather_object(ranks_seen, device_identity(rank, dev_index))
+        distinct = len({r["uuid"] or (r["host"], r["device_index"]) for r in ranks_seen})
+        if backend == "nccl" and distinct != world:
+            # a SCALE line whose RCCL ranks share GPUs is not a scaling measurement: every rank refuses, before any clip is made
+            raise SystemExit(f"bench.py: {world} RCCL ranks sit on {distinct} distinct GPUs ({[r['pci'] for r in ranks_seen]}): one rank per GPU is the contract")
 
     import colorvideovdp_amd as cv
     from colorvideovdp_amd.heatmap_writers import HeatmapFrameMeans
@@ -486,16 +504,34 @@ def main():
     for _ in range(args.steps):
         jod, stats = step()
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0            # this rank's K steps, before it waits for the others
     if dist_on:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     prof = None if args.no_profile else m.profile_read()
     m.profile(False)
     power = power_probe(step, torch.cuda.synchronize) if (world == 1 and not args.no_profile and not args.no_power_probe) else None
+    per_rank = None
     if dist_on:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt)
+        # what makes the first hardware SCALE line explain itself: every rank's own time for the K steps (the value
+        # uses the MAX of the barrier-to-barrier times, as the contract says), and the step's only collective timed on its own
+        gdev = device if backend == "nccl" else torch.device("cpu")
+        mine = torch.tensor([dt, dt_own], device=gdev, dtype=torch.float64)
+        allt = [torch.empty_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allt, mine)
+        per_rank = [[float(x[0]), float(x[1])] for x in allt]
+        dt = max(x[0] for x in per_rank)
+        from colorvideovdp_amd.sharding import all_gather_frames
+        q_local = torch.zeros((1, 4, count, int(stats["Q_per_ch"].shape[-1])), dtype=torch.float32, device=device)
+        n_ag = 20
+        all_gather_frames(q_local, n_total)           # (first call: communicator / buffers)
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        ta = time.perf_counter()
+        for _ in range(n_ag):
+            all_gather_frames(q_local, n_total)
+        torch.cuda.synchronize()
+        allgather_us = (time.perf_counter() - ta) / n_ag * 1e6
     if rank != 0:
         if dist_on:
             torch.distributed.destroy_process_group()
@@ -513,15 +549,30 @@ def main():
     out = {
         "metric": "Mpixels/s", "value": round(mpix, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": cv.COMPUTE_DTYPE, "data": "synthetic",
         "config": {"workload": what, "name": args.workload, "frames_total": n_total, "frames_this_gpu": count, "input_dtype": dtype,
+                   "arithmetic": cv.COMPUTE_DTYPE + " in every kernel (8 / 10 / 16-bit and Y'CbCr samples are unpacked to fp32 by the first kernel; "
+                                 "block partial sums are finished in f64)",
+                   "library_build": "%s (compiled HIP %d, runtime HIP %d)" % _capi_build_info(),
                    "heatmap": heat or "none", "frame_generator": gen, "block_frames": getattr(m, "last_block_frames", None)},
         "jod": round(float(jod), 5), "spinup_steps": n_spin,
     }
     if dist_on:
+        distinct = len({r["uuid"] or (r["host"], r["device_index"]) for r in ranks_seen})
+        halo = [min(fl - 1, plan_frame_shard(n_total, r, world)[0]) for r in range(world)]
         out["config"]["collectives"] = {"backend": torch.distributed.get_backend(), "world": world,
                                         "per_step": "one all-gather of the Q_per_ch shards", "spin_up": "barrier + one broadcast word per step",
-                                        "ranks_seen": ranks_seen, "distinct_devices": len({r["uuid"] or (r["host"], r["device_index"]) for r in ranks_seen})}
+                                        "ranks_seen": ranks_seen, "distinct_devices": distinct,
+                                        "allgather_us": round(allgather_us, 1),
+                                        "allgather_note": f"the step's only collective ([1,4,{count},bands] fp32 per rank) timed alone, {n_ag} calls back to back "
+                                                          "after the timed region (host clock around synchronize)",
+                                        "halo_frames_per_rank": halo,
+                                        "halo_note": f"real frames before the shard that only pass through the temporal kernel (rank 0 pads instead); "
+                                                     f"{fl - 1} of {count} = {(fl - 1) / max(count, 1):.1%} more frames to read and convert on ranks > 0"}
+        out["per_rank_ms"] = [round(x[1] / args.steps * 1e3, 3) for x in per_rank]
+        out["per_rank_ms_note"] = ("every rank's own K steps / K, before the closing barrier (ms_per_step is the MAX over ranks of the barrier-to-barrier "
+                                   "time, as the contract says); the spread says which rank was slow, rank 0 carries no halo frames")
+        out["config"]["per_rank_ms"] = out["per_rank_ms"]      # (the driver's record keeps `config`; unknown top-level keys only by name)
     if golden is not None and gen == "cpu":
         if (clip.checksum_test, clip.checksum_ref) == (int(golden["checksum_test"]), int(golden["checksum_ref"])):
             q, qr = stats["Q_per_ch"].astype(np.float64), golden["Q_per_ch"].astype(np.float64)
@@ -531,6 +582,10 @@ def main():
             # the parity tests' criterion (tests/test_gpu_parity.py: rtol 2e-4, atol 2e-6): 1.0 = at the tolerance
             out["q_per_ch_max_err_over_test_tolerance"] = float(np.max(np.abs(q - qr) / (2e-4 * np.abs(qr) + 2e-6)))
             out["reference_fixture"] = f"tests/golden/{GOLDEN[(args.workload, dtype)]}.npz (the real reference on this very clip, oracle/make_goldens_bench.py)"
+            # BASELINE.json's metric is "Mpixels/s + JOD delta vs reference": the second half rides in `config`, which the driver's record keeps
+            out["config"]["parity"] = {k: out[k] for k in ("jod_reference", "jod_delta_vs_reference", "q_per_ch_max_rel_err_vs_reference",
+                                                           "q_per_ch_max_err_over_test_tolerance", "reference_fixture")}
+            out["config"]["parity"]["tolerance"] = "JOD |delta| <= 1e-3 (north_star); Q_per_ch rtol 2e-4 + atol 2e-6 (this build's tests)"
         else:
             out["jod_delta_vs_reference"] = None      # this torch build's CPU generator does not reproduce the fixture's frames
     fused_levels = m.fused_levels
@@ -546,7 +601,7 @@ def main():
                               "note": "fewer algorithmic bytes than round 2 (162.6 for f32): fused band kernels read a level once, so the "
                                       "same pixel rate is a smaller fraction" if fused_levels > 0 else "no fused levels for this clip"},
     }
-    ceil = measured_copy_ceiling()
+    ceil = measured_copy_ceiling(build * W * H * count / 2 / 1e6)      # bytes read ~ bytes written per step: one "side" of a copy
     if ceil is not None:
         for k in ("survey_model", "build_algorithmic"):
             out["path_roofline"][k]["frac_of_measured_copy_per_gpu"] = round(out["path_roofline"][k]["achieved_GBs"] / ceil["GBs"], 4)
@@ -575,7 +630,17 @@ def main():
                 traffic = (ktraffic or {}).get("band_level0", {}).get("hbm_bytes_per_launch")
                 traffic_note = ("FETCH_SIZE x 2 + WRITE_SIZE per launch from separate --pmc passes over these kernel sources (stamp matches; "
                                 f"library binary {'identical' if have.get('lib_sha256') == stamp['lib_sha256'] else 'rebuilt from the same sources'})")
-        out["roofline"] = {"bound": "hbm", "kernel": ("k_band4s level 0 (front waves: ring, 5x5 reduce to level 1, expand, luminance terms; back waves: contrast, CSF, masking, "
+        sq0 = ((ktraffic or {}).get("band_level0") or {}).get("sq") or {}
+        # `bound` is what the counters of the stamped passes say holds the kernel back: VALU issue when its HBM traffic is within 1.25 x of the
+        # algorithmic bytes, the pipes are >= 60 % busy and the achieved rate is below half the HBM peak; "hbm" otherwise and whenever
+        # there are no counters for these sources.  achieved / peak / frac stay the HBM accounting of the bench contract either way.
+        valu_bound = bool(traffic and sq0.get("valu_busy") and traffic <= 1.25 * BAND0_BYTES_PER_PIXEL * W * H * frames_per_launch
+                          and sq0["valu_busy"] >= 0.6 and ach < 0.5 * HBM_PEAK_GBS)
+        out["roofline"] = {"bound": "valu" if valu_bound else "hbm",
+                           "bound_note": ("VALU issue at the shader clock the socket power limit leaves (counters: traffic = %.2f x algorithmic bytes, VALU %.0f %% busy); "
+                                          "achieved / peak / frac below are the HBM accounting" % (traffic / (BAND0_BYTES_PER_PIXEL * W * H * frames_per_launch), 100 * sq0["valu_busy"]))
+                                         if valu_bound else "HBM accounting (no counters stamped to these sources say otherwise)",
+                           "kernel": ("k_band4s level 0 (front waves: ring, 5x5 reduce to level 1, expand, luminance terms; back waves: contrast, CSF, masking, "
                                                       "blurs, pooling) + k_band4s_edge (the same layout's EDGE body) on the border strips as a second launch beside it: the pair is timed") if fused_levels > 0 else
                                                      "k_band4<4> level 0 (fused expand/contrast/CSF/masking/blur/pooling)",
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -583,8 +648,7 @@ def main():
                            "algorithmic_bytes_per_launch": BAND0_BYTES_PER_PIXEL * W * H * frames_per_launch}
         sq = ((ktraffic or {}).get("band_level0") or {}).get("sq")
         if sq:
-            # what holds this kernel back when it is not the memory system (same stamped counter passes): it is a VALU / latency kernel --
-            # "bound": "hbm" above is the accounting the bench contract asks for, not a claim that HBM limits it
+            # what holds this kernel back when it is not the memory system (same stamped counter passes)
             out["roofline"]["valu"] = {"busy": sq.get("valu_busy"), "instructions_per_launch": sq.get("valu_instructions_per_launch"),
                                        "waves_waiting_frac": sq.get("waves_waiting_frac"), "workgroups": sq.get("workgroups"),
                                        "source": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32), profiles/*_pmc_sq_counters.txt (tools/sq_counters.sh)"}

@@ -8,3 +8,4 @@ from .video_source_yuv import video_source_yuv_file
 from .vq_metric import register_metric, vq_exception, vq_metric, vq_metric_dict
 
 __version__ = "0.3.0"
+COMPUTE_DTYPE = "f32"      # the arithmetic of every kernel (integer / fp16 / Y'CbCr samples are unpacked to fp32 by the first kernel of the path)

@@ -12,7 +12,7 @@ MAX_WINDOW = 256
 CSF_NODES = 32
 PROF_N = 6
 PROF_NAMES = ("photometry", "temporal_fir", "pyr_reduce", "band_level0", "band_rest", "heatmap")
-ABI_VERSION = 12
+ABI_VERSION = 13
 RESIZE_MODES = {"nearest": 0, "bilinear": 1, "bicubic": 2, "area": 3}   # CVVDP_RESIZE_*
 
 U8, U16, F16, F32, F32_DKL, YUV8, YUV16 = range(7)
@@ -73,6 +73,9 @@ class YuvFormat(C.Structure):
 SYMBOLS = {
     "cvvdp_abi_version": (C.c_int, []),
     "cvvdp_build_flags": (C.c_int, []),
+    "cvvdp_build_info": (C.c_char_p, []),
+    "cvvdp_compiled_hip_version": (C.c_int, []),
+    "cvvdp_runtime_hip_version": (C.c_int, []),
     "cvvdp_fused_levels": (C.c_int, [C.c_void_p]),
     "cvvdp_struct_sizes": (None, [C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "cvvdp_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_void_p)]),
@@ -137,8 +140,24 @@ def lib():
         l.cvvdp_struct_sizes(C.byref(sp), C.byref(sc))
         if (sp.value, sc.value) != (C.sizeof(Params), C.sizeof(Clip)):
             raise ImportError(f"struct layout mismatch: library {(sp.value, sc.value)} vs binding {(C.sizeof(Params), C.sizeof(Clip))}")
+        # The band kernels' hand-issued loads were checked against the register allocation of the compiler the library was built with
+        # (cvvdp_build_info; bench.py prints it in config.library_build).  The HIP runtime in the process is whatever torch's wheel
+        # bundles (here 7.0 under a 7.2 toolchain: a minor-version gap is the normal state and says nothing), so only another MAJOR
+        # version -- a different code-object / launch ABI generation -- is reported.
+        built, running = l.cvvdp_compiled_hip_version(), l.cvvdp_runtime_hip_version()
+        if running and built // 10000000 != running // 10000000:
+            import warnings
+            warnings.warn(f"libcvvdp_hip.so was built and ISA-checked with {l.cvvdp_build_info().decode()}; the HIP runtime in this process is "
+                          f"{running // 10000000}.{running // 100000 % 100}.{running % 100000}: rebuild with `make -C colorvideovdp_amd/csrc` "
+                          "(the build re-runs the check)", RuntimeWarning)
         _lib = l
     return _lib
+
+
+def build_info():
+    """(toolchain string of the loaded library, compiled HIP version, runtime HIP version)."""
+    l = lib()
+    return l.cvvdp_build_info().decode(), l.cvvdp_compiled_hip_version(), l.cvvdp_runtime_hip_version()
 
 
 class CoreError(RuntimeError):

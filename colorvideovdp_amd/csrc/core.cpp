@@ -410,6 +410,23 @@ int cvvdp_build_flags(void) {
   return f;
 }
 
+#define CVVDP_STR2(x) #x
+#define CVVDP_STR(x) CVVDP_STR2(x)
+const char* cvvdp_build_info(void) {
+#ifdef __clang_version__
+#define CVVDP_COMPILER "clang " __clang_version__
+#else
+#define CVVDP_COMPILER "host compiler " __VERSION__      /* (tests/test_host_sanitize.py builds this file with g++) */
+#endif
+  return CVVDP_COMPILER "; HIP " CVVDP_STR(HIP_VERSION_MAJOR) "." CVVDP_STR(HIP_VERSION_MINOR) "." CVVDP_STR(HIP_VERSION_PATCH) "; gfx950";
+}
+int cvvdp_compiled_hip_version(void) { return HIP_VERSION; }
+int cvvdp_runtime_hip_version(void) {
+  int v = 0;
+  if (hipRuntimeGetVersion(&v) != hipSuccess) return 0;
+  return v;
+}
+
 int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
   if (!h || !clip) return CVVDP_E_ARG;
   if (h->band_stream && (h->band_pending[0] || h->band_pending[1])) {   // re-configuring with band work in flight

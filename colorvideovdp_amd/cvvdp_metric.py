@@ -113,13 +113,50 @@ class cvvdp(vq_metric):
         except Exception:
             pass
 
+    _INT_PARAMETERS = ("pu_dilate", "filter_len")      # the only numeric parameters that are integers by meaning (the betas are exponents)
+    _LIST_LENGTHS = {"mask_q": 4, "xcm_weights": 16, "baseband_weight": 4, "sigma_tf": 4, "beta_tf": 4}
+
+    def _param_device(self):
+        return self.device if torch.cuda.is_available() else torch.device("cpu")
+
     def __getattr__(self, name):
-        # only reached when normal lookup fails: the numeric model parameters as the reference's tensor attributes (read-only view
-        # of self.parameters; to change them use update_from_checkpoint, which also re-makes the core's handle)
+        # only reached when normal lookup fails: the numeric model parameters as the reference's tensor attributes on the metric's
+        # device (cvvdp_metric.py:153-219 keeps them as tensors on self.device) -- a view of self.parameters
         p = self.__dict__.get("parameters")
         if p is not None and name in p and not isinstance(p[name], (str, bool)):
-            return torch.as_tensor(p[name], dtype=torch.float32 if isinstance(p[name], (float, list)) else None)
+            return torch.as_tensor(p[name], dtype=torch.float32 if isinstance(p[name], (float, list)) else None, device=self._param_device())
         raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+
+    def __setattr__(self, name, value):
+        # `metric.mask_c = torch.tensor(..)` is how a parameter is changed on the reference (its parameters ARE attributes): here the value
+        # goes into self.parameters and the core's handle is re-made from it, or the assignment raises and nothing changes
+        # (`filter_len` is per-call state on the reference too: predict overwrites it with the length of the filters it made, :338)
+        p = self.__dict__.get("parameters")
+        if p is not None and name in p and name != "filter_len" and not isinstance(p[name], (str, bool)):
+            q = dict(p)
+            q[name] = self._parameter_value(name, value, p[name])
+            self._set_parameters(q)
+            return
+        object.__setattr__(self, name, value)
+
+    @classmethod
+    def _parameter_value(cls, name, value, current):
+        """A tensor / array / number handed in for parameter `name` as the plain float, int or list of floats self.parameters holds.
+        Scalars stay floats (the core's parameters are all fp32: a checkpoint's beta_tch = 3.7 must not become 3); the two parameters
+        that are integers by meaning refuse a fractional value; a list keeps the length the kernels are built for."""
+        v = value.detach().to("cpu", torch.float32) if torch.is_tensor(value) else torch.as_tensor(np.asarray(value), dtype=torch.float32)
+        if isinstance(current, list):
+            if v.dim() != 1 or v.numel() != len(current):
+                raise ValueError(f"parameter '{name}' holds {len(current)} values, got shape {tuple(v.shape)}")
+            return [float(x) for x in v.tolist()]
+        if v.numel() != 1:
+            raise ValueError(f"parameter '{name}' is a scalar, got shape {tuple(v.shape)}")
+        x = float(v.reshape(()).item())
+        if name in cls._INT_PARAMETERS:
+            if x != round(x):
+                raise ValueError(f"parameter '{name}' is an integer, got {x}")
+            return int(round(x))
+        return x
 
     def train(self, do_training=True):
         self.training_mode = do_training
@@ -131,11 +168,9 @@ class cvvdp(vq_metric):
         self._config_paths = list(config_paths)
         self._set_parameters(json2dict(self.parameters_file))
 
-    def _set_parameters(self, p):
-        """Second half of the reference's load_config: the parameter dictionary becomes the metric's state and the core's handle is
-        re-made from it.  `self.parameters` is what the kernels are configured from; its numeric entries can also be READ as tensor
-        attributes of the same name (`metric.mask_c`, ...: `__getattr__`), the way the reference keeps them (cvvdp_metric.py:153-219)."""
-        self.parameters = p
+    @classmethod
+    def _validate_parameters(cls, p):
+        """Everything _set_parameters / _make_handle would stumble over, checked BEFORE any state changes."""
         if p["masking_model"] != "mult-mutual" or p["contrast"] != "weber_g1" or p["dclamp_type"] != "soft" \
                 or p["csf"] != "weber_fixed_size" or p["xchannel_masking"] != "on" or "block_channels" in p \
                 or p.get("temp_filter", "default") != "default" or "ch_chrom_w" not in p or "mask_q" not in p:
@@ -143,15 +178,46 @@ class cvvdp(vq_metric):
                                "(masking 'mult-mutual', contrast 'weber_g1', soft clamp, csf 'weber_fixed_size', cross-channel masking on)")
         if p["beta"] != 2:
             raise RuntimeError("The fused band kernel implements the spatial p-norm for beta=2 only")
-        self.version = p["version"]
-        self.pu_dilate = p["pu_dilate"]
-        if self.pu_dilate not in (0, 3):
+        if p["pu_dilate"] not in (0, 3):
             raise RuntimeError("pu_dilate must be 0 or 3")
-        self.csf_table = hs.CsfTable(load_config("csf_lut_weber_fixed_size.json", self._config_paths))
-        self.jod_a, self.jod_exp = f32(p["jod_a"]), f32(p["jod_exp"])
-        self.baseband_weight = np.asarray(p["baseband_weight"], dtype=f32)
-        self.ch_w = np.asarray([1.0, p["ch_chrom_w"], p["ch_chrom_w"], p["ch_trans_w"]], dtype=f32)
-        self._make_handle()
+        for name, n in cls._LIST_LENGTHS.items():
+            if name in p and (not isinstance(p[name], (list, tuple)) or len(p[name]) != n):
+                raise RuntimeError(f"parameter '{name}' must be a list of {n} numbers")
+        for name in ("mask_p", "mask_c", "d_max", "sensitivity_correction", "beta_t", "beta_tch", "beta_sch", "jod_a", "jod_exp", "image_int",
+                     "ch_chrom_w", "ch_trans_w"):
+            if isinstance(p.get(name), (str, bool)) or not np.isfinite(float(p[name])):
+                raise RuntimeError(f"parameter '{name}' must be a finite number")
+
+    def _set_parameters(self, p):
+        """Second half of the reference's load_config: the parameter dictionary becomes the metric's state and the core's handle is
+        re-made from it.  `self.parameters` is what the kernels are configured from; its numeric entries are also tensor attributes of
+        the same name (`metric.mask_c`, ...: `__getattr__` / `__setattr__`), the way the reference keeps them (cvvdp_metric.py:153-219).
+        All or nothing: a dictionary that does not validate, or from which no handle can be made, leaves the metric as it was."""
+        self._validate_parameters(p)
+        d = self.__dict__
+        keys = ("parameters", "version", "pu_dilate", "csf_table", "_jod_a", "_jod_exp", "_baseband_weight", "_ch_w")
+        prev = {k: d[k] for k in keys if k in d}
+        try:
+            d["parameters"] = p
+            d["version"] = p["version"]
+            d["pu_dilate"] = p["pu_dilate"]
+            d["csf_table"] = hs.CsfTable(load_config("csf_lut_weber_fixed_size.json", self._config_paths))
+            d["_jod_a"], d["_jod_exp"] = f32(p["jod_a"]), f32(p["jod_exp"])
+            d["_baseband_weight"] = np.asarray(p["baseband_weight"], dtype=f32)
+            d["_ch_w"] = np.asarray([1.0, p["ch_chrom_w"], p["ch_chrom_w"], p["ch_trans_w"]], dtype=f32)
+            self._make_handle()
+        except Exception:
+            for k in keys:
+                d.pop(k, None)
+            d.update(prev)
+            if "parameters" in prev:
+                self._make_handle()
+            raise
+
+    @property
+    def ch_w(self):
+        """Per-channel weights [1, ch_chrom_w, ch_chrom_w, ch_trans_w] (cvvdp_metric.py:604-607 builds them per call), as a tensor."""
+        return torch.as_tensor(self._ch_w, device=self._param_device())
 
     def _make_handle(self):
         self._cfg_version = getattr(self, "_cfg_version", 0) + 1
@@ -177,7 +243,7 @@ class cvvdp(vq_metric):
         P.blur_taps[:] = hs.gaussian_taps(13, 3.0).tolist()
         P.beta, P.beta_t, P.beta_tch, P.beta_sch = p["beta"], p["beta_t"], p["beta_tch"], p["beta_sch"]
         P.jod_a, P.jod_exp, P.image_int = p["jod_a"], p["jod_exp"], p["image_int"]
-        P.ch_w[:] = self.ch_w.tolist()
+        P.ch_w[:] = self._ch_w.tolist()
         P.baseband_weight[:] = p["baseband_weight"]
         P.csf_logL_first, P.csf_logL_last = float(self.csf_table.log_L[0]), float(self.csf_table.log_L[-1])
         lib = _capi.lib()
@@ -201,13 +267,13 @@ class cvvdp(vq_metric):
             if not key.startswith(prefix):
                 continue
             name = key[len(prefix):]
-            v = value.detach().to(torch.float32) if torch.is_tensor(value) else torch.as_tensor(value, dtype=torch.float32)
             if isinstance(p.get(name), (str, bool)):
                 raise RuntimeError(f"checkpoint entry '{key}' would replace the non-numeric parameter '{name}'")
             if name in p:
-                p[name] = v.tolist() if v.dim() > 0 else (int(v.item()) if isinstance(p[name], int) else float(v.item()))
+                p[name] = self._parameter_value(name, value, p[name])      # floats stay floats; wrong-length lists raise here
             else:
-                extra[name] = v.to(self.device)        # the reference sets ANY attribute; ones the model does not read stay attributes
+                v = value.detach().to(torch.float32) if torch.is_tensor(value) else torch.as_tensor(value, dtype=torch.float32)
+                extra[name] = v.to(self._param_device())   # the reference sets ANY attribute; ones the model does not read stay attributes
         self._set_parameters(p)
         for name, v in extra.items():
             setattr(self, name, v)
@@ -835,14 +901,14 @@ class cvvdp(vq_metric):
         return jod
 
     def get_ch_weights(self, no_channels):
-        return self.ch_w[0:no_channels].reshape(1, -1, 1, 1)
+        return self._ch_w[0:no_channels].reshape(1, -1, 1, 1)
 
     def met2jod(self, Q):
         """cvvdp_metric.py:646-658 (numpy, used by export_distogram)."""
         Q = np.asarray(Q, dtype=f32)
         Q_t = f32(0.1)
-        a_p = self.jod_a * np.power(Q_t, self.jod_exp - f32(1.0))
-        return np.where(Q <= Q_t, f32(10.0) - a_p * Q, f32(10.0) - self.jod_a * np.power(np.maximum(Q, Q_t), self.jod_exp)).astype(f32)
+        a_p = self._jod_a * np.power(Q_t, self._jod_exp - f32(1.0))
+        return np.where(Q <= Q_t, f32(10.0) - a_p * Q, f32(10.0) - self._jod_a * np.power(np.maximum(Q, Q_t), self._jod_exp)).astype(f32)
 
     def full_name(self):
         return "ColorVideoVDP"
@@ -885,7 +951,7 @@ class cvvdp(vq_metric):
         if q.shape[0] != 1:
             raise vq_exception("Exporting distograms in batch mode is not supported")
         n_ch = q.shape[1]
-        q[..., -1] *= self.baseband_weight[:n_ch].reshape(-1, 1)     # the baseband has its own weight per channel
+        q[..., -1] *= self._baseband_weight[:n_ch].reshape(-1, 1)     # the baseband has its own weight per channel
         q *= self.get_ch_weights(n_ch) * n_ch
         loss = 10.0 - self.met2jod(q)
         if jod_max is None:

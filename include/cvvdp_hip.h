@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define CVVDP_ABI_VERSION 12
+#define CVVDP_ABI_VERSION 13
 #define CVVDP_MAX_FILTER_LEN 65 /* 0.25 s at up to 256 fps, cvvdp_metric.py:1059 */
 #define CVVDP_MAX_LEVELS 16
 #define CVVDP_MAX_WINDOW 256    /* filter_len - 1 + frames per block */
@@ -154,6 +154,16 @@ int cvvdp_abi_version(void);
 #define CVVDP_BUILD_SAFE_LOADS 2
 #define CVVDP_BUILD_DIAG 4
 int cvvdp_build_flags(void);
+/* The toolchain this library was compiled -- and its hand-scheduled band kernels statically checked (tools/check_band4_isa.py, run by
+ * `make` on the assembly of the linked objects) -- with: "clang <version>; HIP <major.minor.patch>; gfx950".  The hand-issued loads of
+ * the band kernels are verified against THAT compiler's register allocation; a binding compares the HIP version here with the
+ * runtime's (cvvdp_runtime_hip_version) and says so when they differ (colorvideovdp_amd/_capi.py warns; results are guarded either
+ * way by tests/test_safe_loads.py).  Static string, never NULL. */
+const char* cvvdp_build_info(void);
+/* HIP version the library was compiled with (HIP_VERSION = major * 10000000 + minor * 100000 + patch) and the version of the HIP
+ * runtime it is running on (hipRuntimeGetVersion; 0 when the call fails, e.g. without a device). */
+int cvvdp_compiled_hip_version(void);
+int cvvdp_runtime_hip_version(void);
 /* sizeof(cvvdp_params), sizeof(cvvdp_clip) as compiled, so a binding can verify its struct layout. */
 void cvvdp_struct_sizes(int32_t* params_bytes, int32_t* clip_bytes);
 

@@ -24,6 +24,7 @@
 static int g_live_streams = 0, g_live_events = 0;
 extern "C" {
 hipError_t hipGetLastError(void) { return hipSuccess; }
+hipError_t hipRuntimeGetVersion(int* v) { *v = HIP_VERSION; return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "stub"; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(new int(0)); ++g_live_events; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }

@@ -91,8 +91,8 @@ __global__ __launch_bounds__(BT) void k_band(BandArgs a) {
         for (int p = t >> 7; p < NP; p += 2) {
           const float* cp = gc + p * gcps + (cx_lo + ci);
           float v;
-          if (odd) v = cp[(int64_t)my * Wc] * eo + cp[(int64_t)yb * Wc] * eo;
-          else v = cp[(int64_t)ya * Wc] * e0 + cp[(int64_t)my * Wc] * e1 + cp[(int64_t)yb * Wc] * e0;
+          if (odd) v = expand_odd(cp[(int64_t)my * Wc], cp[(int64_t)yb * Wc], eo);
+          else v = expand_even(cp[(int64_t)ya * Wc], cp[(int64_t)my * Wc], cp[(int64_t)yb * Wc], e0, e1);
           s_ve[p][ci] = v;
         }
       }
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(BT) void k_band(BandArgs a) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         gv[p] = g[p * gps + (int64_t)rr * W + xx];
-        if (xx & 1) ex[p] = s_ve[p][cb] * eo + s_ve[p][cc] * eo;               // lpyr_dec.py:234-237
-        else ex[p] = s_ve[p][ca] * e0 + s_ve[p][cb] * e1 + s_ve[p][cc] * e0;
+        if (xx & 1) ex[p] = expand_odd(s_ve[p][cb], s_ve[p][cc], eo);               // lpyr_dec.py:234-237
+        else ex[p] = expand_even(s_ve[p][ca], s_ve[p][cb], s_ve[p][cc], e0, e1);
       }
       const float Lt = fmaxf(ex[0], 0.01f), Lr = fmaxf(ex[1], 0.01f);     // lpyr_dec.py:394
       const float rLt = fast_rcp(Lt), rLr = fast_rcp(Lr);

@@ -76,7 +76,11 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
 #ifdef CVVDP_SAFE_LOADS
   constexpr bool F_SAFE = true;       // `make safe`: every instantiation (tests/test_safe_loads.py)
 #else
-  constexpr bool F_SAFE = HEAT || FEAT;
+  // EDGE == 1 (round 6): since the border strips of W % 4 == 0 frames run k_band4s_edge, the plain EDGE == 1 instantiation only serves the
+  // one-wave A/B layout (cvvdp_clip.band_layout = 1, a test reference).  Its hand-issued loads held only as long as the register
+  // allocator happened to keep the ring in place: fixing the expand's operation order (kernels.h expand_even) made it copy ring
+  // registers inside the loop, the ISA check failed the build.  A kernel nobody's product path runs is not worth that: ordinary loads.
+  constexpr bool F_SAFE = HEAT || FEAT || EDGE == 1;
 #endif
   constexpr int NP = 2 * NCH;
   __shared__ __attribute__((aligned(16))) float2 s_ve[2][NP][F_VE / 2];
@@ -160,10 +164,10 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
     float o[4];
     if constexpr (decltype(odd_row)::value) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = m1[i] * eo + m2[i] * eo;
+      for (int i = 0; i < 4; ++i) o[i] = expand_odd(m1[i], m2[i], eo);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = m0[i] * e0 + m1[i] * e1 + m2[i] * e0;
+      for (int i = 0; i < 4; ++i) o[i] = expand_even(m0[i], m1[i], m2[i], e0, e1);
     }
     s_ve[buf][2 * c][2 + j] = make_float2(o[0], o[1]);           // coarse columns cb+2j, cb+2j+1 of the test plane ...
     s_ve[buf][2 * c + 1][2 + j] = make_float2(o[2], o[3]);       // ... and of the reference plane
@@ -268,10 +272,10 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
     const float2 p1 = row[j + 2];
     const float2 p2 = row[j + 3];
     const float A = p0.y, B = p1.x, C = p1.y, D = p2.x;
-    ex[0] = A * e0 + B * e1 + C * e0;
-    ex[1] = B * eo + C * eo;
-    ex[2] = B * e0 + C * e1 + D * e0;
-    ex[3] = C * eo + D * eo;
+    ex[0] = expand_even(A, B, C, e0, e1);
+    ex[1] = expand_odd(B, C, eo);
+    ex[2] = expand_even(B, C, D, e0, e1);
+    ex[3] = expand_odd(C, D, eo);
   };
 
   // per-column luminance terms of one row, shared by all channels (band4.hip lum_prep)
@@ -282,8 +286,8 @@ __device__ __forceinline__ void band4f_body(const BandArgs& a) {
     const float* yR = reinterpret_cast<const float*>(&s_ve[buf][1][0]);
     for (int col = t; col < 256; col += 64 * NCH) {
       const int e = 4 + (col >> 1);
-      const float eyT = yT[e - 1] * lwa + yT[e] * lwb + yT[e + 1] * lwc;
-      const float eyR = yR[e - 1] * lwa + yR[e] * lwb + yR[e + 1] * lwc;
+      const float eyT = __builtin_fmaf(yT[e + 1], lwc, __builtin_fmaf(yT[e], lwb, yT[e - 1] * lwa));   // (kernels.h expand_even / expand_odd: the reference's order)
+      const float eyR = __builtin_fmaf(yR[e + 1], lwc, __builtin_fmaf(yR[e], lwb, yR[e - 1] * lwa));
       const float Lt = fmaxf(eyT, 0.01f), Lr = fmaxf(eyR, 0.01f);              // lpyr_dec.py:394
       float ind = fast_log2(Lr) * ind_k1 - ind_k0;
       ind = __builtin_amdgcn_fmed3f(ind, 0.0f, (float)(CVVDP_CSF_NODES - 1));  // clamp (interp.py:93)

@@ -64,8 +64,11 @@ struct cvvdp_handle {
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   // frames whose width is not a multiple of 8: the one or two strips at the right image edge (RAGGED instantiation of k_band4) run
   // on their own stream beside the aligned strips of the same level
-  hipStream_t edge_stream = nullptr;
-  hipEvent_t ev_edge_fork = nullptr, ev_edge_join = nullptr;
+  // edge streams: the border strips of a level run beside its other strips.  One per stream a level can be enqueued on (0: the caller's,
+  // 1 / 2: the side streams of the band stage), each with its own fork / join events -- two levels in flight on different streams never
+  // share an event or serialise their border launches on one stream
+  hipStream_t edge_stream[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_edge_fork[3] = {nullptr, nullptr, nullptr}, ev_edge_join[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_reduce[2] = {nullptr, nullptr}, ev_band[2] = {nullptr, nullptr};
   bool band_pending[2] = {false, false};
 };
@@ -285,16 +288,17 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
       launch_heat_init(a.hstats, items, s);
       h->last_range_done = true;
     }
+    const int es = s == s_main ? 0 : 1 + (l & 1);      // which edge stream goes with the stream this level is on
     if (fused || (lv.vec4 && lv.split_edge)) {
-      if (!h->edge_stream) {
-        if (hipStreamCreateWithFlags(&h->edge_stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_edge_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_edge_join, hipEventDisableTiming) != hipSuccess)
+      if (!h->edge_stream[es]) {
+        if (hipStreamCreateWithFlags(&h->edge_stream[es], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_edge_fork[es], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_edge_join[es], hipEventDisableTiming) != hipSuccess)
           return fail(h, CVVDP_E_HIP, "cannot create the edge-strip stream of the band stage");
       }
-      s_edge = h->edge_stream;
-      (void)hipEventRecord(h->ev_edge_fork, s);
-      (void)hipStreamWaitEvent(s_edge, h->ev_edge_fork, 0);
+      s_edge = h->edge_stream[es];
+      (void)hipEventRecord(h->ev_edge_fork[es], s);
+      (void)hipStreamWaitEvent(s_edge, h->ev_edge_fork[es], 0);
     }
     if (fused) {
       a.g1_out = gbase(h, l + 1, set);
@@ -307,8 +311,8 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
       launch_band(a, lv.blur, s);
     }
     if (s_edge != s) {
-      (void)hipEventRecord(h->ev_edge_join, s_edge);
-      (void)hipStreamWaitEvent(s, h->ev_edge_join, 0);
+      (void)hipEventRecord(h->ev_edge_join[es], s_edge);
+      (void)hipStreamWaitEvent(s, h->ev_edge_join[es], 0);
     }
     FinalizeArgs f{};
     f.partial = a.partial; f.items = items; f.nblk = lv.n_strip * lv.n_seg; f.nch = nch; f.P = (int)lv.P;
@@ -395,9 +399,11 @@ void cvvdp_destroy(cvvdp_handle* h) {
     if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
   }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  if (h->edge_stream) { (void)hipStreamSynchronize(h->edge_stream); (void)hipStreamDestroy(h->edge_stream); }
-  if (h->ev_edge_fork) (void)hipEventDestroy(h->ev_edge_fork);
-  if (h->ev_edge_join) (void)hipEventDestroy(h->ev_edge_join);
+  for (int i = 0; i < 3; ++i) {
+    if (h->edge_stream[i]) { (void)hipStreamSynchronize(h->edge_stream[i]); (void)hipStreamDestroy(h->edge_stream[i]); }
+    if (h->ev_edge_fork[i]) (void)hipEventDestroy(h->ev_edge_fork[i]);
+    if (h->ev_edge_join[i]) (void)hipEventDestroy(h->ev_edge_join[i]);
+  }
   delete h;
 }
 
@@ -539,7 +545,9 @@ int cvvdp_configure(cvvdp_handle* h, const cvvdp_clip* clip) {
     const int clip_frames = c.total_frames > 0 ? c.total_frames : 64;
     const int nominal = c.is_video ? std::min(c.heatmap != CVVDP_HEATMAP_NONE ? 16 : 64, clip_frames) : 1;
     static const int seg_rule = dev_knob("CVVDP_FUSED_SEG_RULE", 1);
-    for (int l = 0; seg_rule && c.fuse_mode != 1 && l < h->fuse_levels; ++l) {
+    // (not when the dev knob CVVDP_PIPELINE routes every level to k_band4: the rule prices k_band4s's 512 resident workgroups)
+    static const bool pipe_knob = dev_knob("CVVDP_PIPELINE", 0) != 0;
+    for (int l = 0; seg_rule && !pipe_knob && c.fuse_mode != 1 && l < h->fuse_levels; ++l) {
       Level& lv = h->lv[l];
       const int64_t per_seg = (int64_t)lv.n_strip * nominal * c.batch;
       static const int fused_rows = dev_knob("CVVDP_FUSED_SEG_ROWS", 384);

@@ -34,14 +34,14 @@ __device__ __forceinline__ void heat_recon4(const HeatArgs& a, int item, int y, 
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int cx = min(max(mx - 1 + k, 0), a.Wc - 1);
-    if (y & 1) v[k] = c[(int64_t)my * a.Wc + cx] * o + c[(int64_t)y2 * a.Wc + cx] * o;
-    else v[k] = c[(int64_t)y0 * a.Wc + cx] * e0 + c[(int64_t)my * a.Wc + cx] * e1 + c[(int64_t)y2 * a.Wc + cx] * e0;
+    if (y & 1) v[k] = expand_odd(c[(int64_t)my * a.Wc + cx], c[(int64_t)y2 * a.Wc + cx], o);
+    else v[k] = expand_even(c[(int64_t)y0 * a.Wc + cx], c[(int64_t)my * a.Wc + cx], c[(int64_t)y2 * a.Wc + cx], e0, e1);
   }
   float4 t = *reinterpret_cast<const float4*>(a.recon + (int64_t)item * a.P + (int64_t)y * a.W + x);
-  t.x += v[0] * e0 + v[1] * e1 + v[2] * e0;
-  t.y += v[1] * o + v[2] * o;
-  t.z += v[1] * e0 + v[2] * e1 + v[3] * e0;
-  t.w += v[2] * o + v[3] * o;
+  t.x += expand_even(v[0], v[1], v[2], e0, e1);      // (the reference adds the band to the finished expand: lpyr_dec.py:333)
+  t.y += expand_odd(v[1], v[2], o);
+  t.z += expand_even(v[1], v[2], v[3], e0, e1);
+  t.w += expand_odd(v[2], v[3], o);
   q[0] = t.x; q[1] = t.y; q[2] = t.z; q[3] = t.w;
 }
 

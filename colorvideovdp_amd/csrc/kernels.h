@@ -28,6 +28,18 @@ __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_lo
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_pow(float x, float p) { return fast_exp2(p * fast_log2(x)); }
+
+// One output sample of the pyramid's expand along one axis (lpyr_dec.py:223-239: a 5-tap convolution of the zero-stuffed level), in the
+// OPERATION ORDER OF THE REFERENCE'S conv2d: torch's CPU convolution accumulates the taps in order with fused multiply-adds starting from
+// the first product (verified bit for bit on this torch build, tools/torch_conv_order.py), and the stuffed zeros contribute exactly
+// nothing.  Even sample: taps 0, 2, 4 on coarse samples m-1, m, m+1; odd sample: taps 1, 3 on m, m+1.  At the two coarsest Laplacian
+// bands (a few dozen pixels whose Laplacian is a 1e-4 relative difference of its operands) any other association of the same
+// products moves Q_per_ch by up to 1.5 x the parity tolerance (profiles/r06_order_experiment.txt); left to the compiler, `a*e0 + b*e1 +
+// c*e0` is contracted differently from kernel to kernel.
+__device__ __forceinline__ float expand_even(float m0, float m1, float m2, float e0, float e1) {
+  return __builtin_fmaf(m2, e0, __builtin_fmaf(m1, e1, m0 * e0));
+}
+__device__ __forceinline__ float expand_odd(float m1, float m2, float eo) { return __builtin_fmaf(m2, eo, m1 * eo); }
 #endif
 constexpr float kLog2_10 = 3.3219280948873623f;
 constexpr float kLog10_2 = 0.30102999566398120f;
@@ -139,6 +151,11 @@ struct Reduce2Args {         // two levels per pass: l -> l+1 -> l+2
   float k[5];
 };
 bool reduce2_supported(int H, int W);
+// Levels of at most this many samples are reduced by k_reduce, which reproduces the reference's operation order bit for bit (pyramid.hip);
+// larger ones by the marching kernels.  128 x 128: from there down a level's band has so few pixels that single roundings of the Gaussian
+// level show in Q_per_ch (the thinnest class of the randomised sweeps, tests/test_fuzz_goldens.py).
+constexpr int64_t kReduceRefPixels = 16384;
+bool reduce_takes_ref_kernel(int H, int W);
 void launch_reduce2(const Reduce2Args& a, hipStream_t s);
 
 // ---------------------------------------------------------------- fused band kernel (K3..K7)

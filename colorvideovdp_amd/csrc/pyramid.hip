@@ -4,11 +4,8 @@
 // reduce = separable 5-tap [.05 .25 .4 .25 .05], stride 2, vertical pass first, written in the
 // reference as a zero-padded convolution plus explicit edge terms.  The edge terms are reproduced
 // literally, including the column edge that tests the ROW parity (lpyr_dec.py:206).
-//
-// Tiling: a 256-thread block produces a 32x32 output tile.  The (2*32+3) x (2*32+3) input patch is
-// staged in LDS with coalesced row loads, the vertical pass writes a 32 x 67 intermediate to LDS, the
-// horizontal pass reads it.  Every input pixel is fetched from HBM/L2 once per tile (+ the 3-pixel
-// apron).
+// Small levels: k_reduce, the reference's arithmetic operation for operation; large levels: the marching kernels
+// k_reduce_vec / k_reduce2 (horizontal pass first in registers, no LDS), which round differently.
 #include <algorithm>
 #include <cstdlib>
 #include "kernels.h"
@@ -18,6 +15,39 @@ namespace cvvdp {
 constexpr int RT = 32;            // output tile edge
 constexpr int RIN = 2 * RT + 3;   // input patch edge (67)
 
+// 5-tap dot product with a FIXED operation order -- THE REFERENCE'S: torch's CPU conv2d accumulates the taps in order with fused
+// multiply-adds, starting from the first product (checked bit for bit against this torch build for column and row kernels at sizes
+// from 7x5 to 2160x3840, tools/torch_conv_order.py), and zero padding contributes exactly nothing to such a chain.  The marching kernels
+// below also evaluate the same taps from several inlined copies of their row code (prologue / steady state); left to the compiler,
+// each copy may contract a*b + c*d + ... into FMAs differently, and a row's last bit would then depend on where its segment starts.
+__device__ __forceinline__ float dot5(float a0, float a1, float a2, float a3, float a4, float k0, float k1, float k2, float k3, float k4) {
+  return __builtin_fmaf(a4, k4, __builtin_fmaf(a3, k3, __builtin_fmaf(a2, k2, __builtin_fmaf(a1, k1, a0 * k0))));
+}
+__device__ __forceinline__ float dot2(float a0, float a1, float k0, float k1) { return __builtin_fmaf(a1, k1, a0 * k0); }
+// a product / a sum rounded on its own, never contracted into a fused multiply-add: the reference's edge terms are separate tensor
+// operations (`ya[0] += x[0]*K[1] + x[1]*K[0]`, lpyr_dec.py:195-209: two products, their sum, the in-place add: four roundings)
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float edge2_rn(float v, float x0, float k0, float x1, float k1) { return add_rn(v, add_rn(mul_rn(x0, k0), mul_rn(x1, k1))); }
+
+// The reference's reduce, OPERATION FOR OPERATION (k_reduce_ref): vertical pass first, each pass a dot5 chain, the edge terms as the
+// separately rounded tensor operations they are in lpyr_dec.py:195-209 -- given the same input level, the output level equals torch's
+// bit for bit (tests/test_gpu_parity.py::test_small_levels_reduce_like_the_reference_bit_for_bit).  Levels of at most
+// kReduceRefPixels samples take this kernel (launch_reduce / run_pyramid_and_bands): the two coarsest Laplacian bands of a clip are a
+// few dozen pixels whose Laplacian is a ~1e-4 relative difference of its operands, so one ulp of the Gaussian level is 3 x the
+// Q_per_ch tolerance there, and the horizontal-first marching kernels below -- the same linear operator with another rounding order --
+// put luminance-only clips 1.0-2.6 x outside it (the emulation of both orders on the CPU:
+// profiles/r06_order_experiment.txt).  On large levels the order does not matter (thousands of pixels per band, well-conditioned
+// Laplacians) and the marching kernels are 5 x faster.
+//
+// Tiling: a 256-thread block produces a 32x32 output tile.  The (2*32+3) x (2*32+3) input patch is staged in LDS with coalesced row
+// loads, the vertical pass writes a 32 x 67 intermediate to LDS, the horizontal pass reads it.
 __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
   __shared__ float s_in[RIN][RIN + 1];
   __shared__ float s_v[RT][RIN + 1];
@@ -41,14 +71,14 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
     const int r = e / RIN, c = e - r * RIN;
     const int oy = oy0 + r;
     float v = 0.0f;
-    if (oy < a.Ho) {
+    if (oy < a.Ho && ix0 + c >= 0 && ix0 + c < a.W) {
       const int pr = 2 * r;  // patch row of input row 2*oy-2
-      v = s_in[pr][c] * k0 + s_in[pr + 1][c] * k1 + s_in[pr + 2][c] * k2 + s_in[pr + 3][c] * k3 + s_in[pr + 4][c] * k4;
+      v = dot5(s_in[pr][c], s_in[pr + 1][c], s_in[pr + 2][c], s_in[pr + 3][c], s_in[pr + 4][c], k0, k1, k2, k3, k4);
       // edge terms (lpyr_dec.py:195-199); patch row of input row y is y - iy0
-      if (oy == 0) v += s_in[0 - iy0][c] * k1 + s_in[1 - iy0][c] * k0;
+      if (oy == 0) v = edge2_rn(v, s_in[0 - iy0][c], k1, s_in[1 - iy0][c], k0);
       if (oy == a.Ho - 1) {
-        if (a.H & 1) v += s_in[a.H - 1 - iy0][c] * k3 + s_in[a.H - 2 - iy0][c] * k4;
-        else v += s_in[a.H - 1 - iy0][c] * k4;
+        if (a.H & 1) v = edge2_rn(v, s_in[a.H - 1 - iy0][c], k3, s_in[a.H - 2 - iy0][c], k4);
+        else v = add_rn(v, mul_rn(s_in[a.H - 1 - iy0][c], k4));
       }
     }
     s_v[r][c] = v;
@@ -60,11 +90,11 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
     const int oy = oy0 + r, ox = ox0 + c;
     if (oy >= a.Ho || ox >= a.Wo) continue;
     const int pc = 2 * c;
-    float v = s_v[r][pc] * k0 + s_v[r][pc + 1] * k1 + s_v[r][pc + 2] * k2 + s_v[r][pc + 3] * k3 + s_v[r][pc + 4] * k4;
-    if (ox == 0) v += s_v[r][0 - ix0] * k1 + s_v[r][1 - ix0] * k0;          // lpyr_dec.py:205
+    float v = dot5(s_v[r][pc], s_v[r][pc + 1], s_v[r][pc + 2], s_v[r][pc + 3], s_v[r][pc + 4], k0, k1, k2, k3, k4);
+    if (ox == 0) v = edge2_rn(v, s_v[r][0 - ix0], k1, s_v[r][1 - ix0], k0);                          // lpyr_dec.py:205
     if (ox == a.Wo - 1) {
-      if (a.H & 1) v += s_v[r][a.W - 1 - ix0] * k3 + s_v[r][a.W - 2 - ix0] * k4;  // sic: row parity, :206-207
-      else v += s_v[r][a.W - 1 - ix0] * k4;                                        // :209
+      if (a.H & 1) v = edge2_rn(v, s_v[r][a.W - 1 - ix0], k3, s_v[r][a.W - 2 - ix0], k4);            // sic: row parity, :206-207
+      else v = add_rn(v, mul_rn(s_v[r][a.W - 1 - ix0], k4));                                         // :209
     }
     out[(int64_t)oy * a.Wo + ox] = v;
   }
@@ -78,14 +108,6 @@ __global__ __launch_bounds__(256) void k_reduce(ReduceArgs a) {
 // horizontal (the two passes act on different axes); only fp32 rounding order differs (~1e-7).
 constexpr int RSEG = 32;  // output rows per thread
 typedef float v4f_ __attribute__((ext_vector_type(4)));
-
-// 5-tap dot product with a FIXED operation order.  The marching kernels evaluate the same taps from several inlined
-// copies of their row code (prologue / steady state); left to the compiler, each copy may contract a*b + c*d + ...
-// into FMAs differently, and a row's last bit would then depend on where its segment starts -- i.e. on the block size.
-__device__ __forceinline__ float dot5(float a0, float a1, float a2, float a3, float a4, float k0, float k1, float k2, float k3, float k4) {
-  return __builtin_fmaf(a4, k4, __builtin_fmaf(a3, k3, __builtin_fmaf(a2, k2, __builtin_fmaf(a1, k1, a0 * k0))));
-}
-__device__ __forceinline__ float dot2(float a0, float a1, float k0, float k1) { return __builtin_fmaf(a1, k1, a0 * k0); }
 
 // Every call issues the same four 16-byte loads (no control flow around them), so a thread can keep several rows in
 // flight and wait with exact counts.  Rows and columns outside the image are the reference's zero padding: the
@@ -407,7 +429,11 @@ __global__ __launch_bounds__(256) void k_reduce2(Reduce2Args a) {
   }
 }
 
-bool reduce2_supported(int H, int W) { return (W % 16 == 0 || W >= 32) && H >= 8; }
+// (two levels per pass only while BOTH inputs -- level l and the level l+1 it makes on the way -- are above the size from which the
+// reference's operation order is reproduced, kReduceRefPixels)
+bool reduce2_supported(int H, int W) {
+  return (W % 16 == 0 || W >= 32) && H >= 8 && !reduce_takes_ref_kernel(H, W) && !reduce_takes_ref_kernel((H + 1) / 2, (W + 1) / 2);
+}
 
 void launch_reduce2(const Reduce2Args& a0, hipStream_t s) {
   Reduce2Args a = a0;
@@ -425,7 +451,14 @@ void launch_reduce2(const Reduce2Args& a0, hipStream_t s) {
   else hipLaunchKernelGGL(k_reduce2<false>, grid, dim3(256), 0, s, a);
 }
 
+bool reduce_takes_ref_kernel(int H, int W) { return (int64_t)H * W <= kReduceRefPixels || W < 16 || H < 4; }
+
 void launch_reduce(const ReduceArgs& a, hipStream_t s) {
+  if (reduce_takes_ref_kernel(a.H, a.W)) {
+    dim3 grid((a.Wo + RT - 1) / RT, (a.Ho + RT - 1) / RT, a.n_planes * a.n_img);
+    hipLaunchKernelGGL(k_reduce, grid, dim3(256), 0, s, a);
+    return;
+  }
   if (a.W % 8 == 0 && a.H >= 4) {
     dim3 grid((a.Wo / 4 + 255) / 256, (a.Ho + RSEG - 1) / RSEG, a.n_planes * a.n_img);
     hipLaunchKernelGGL(k_reduce_vec<false>, grid, dim3(256), 0, s, a);
@@ -454,12 +487,12 @@ __global__ __launch_bounds__(256) void k_expand_add(ExpandAddArgs a) {
   const float e0 = a.kx[0], e1 = a.kx[1], o = a.kx[2];
   // vertical first (lpyr_dec.py:229-232), then horizontal (:234-237)
   auto vert = [&](int cx) -> float {
-    if (y & 1) return c[(int64_t)my * a.Wc + cx] * o + c[(int64_t)y2 * a.Wc + cx] * o;
-    return c[(int64_t)y0 * a.Wc + cx] * e0 + c[(int64_t)my * a.Wc + cx] * e1 + c[(int64_t)y2 * a.Wc + cx] * e0;
+    if (y & 1) return expand_odd(c[(int64_t)my * a.Wc + cx], c[(int64_t)y2 * a.Wc + cx], o);
+    return expand_even(c[(int64_t)y0 * a.Wc + cx], c[(int64_t)my * a.Wc + cx], c[(int64_t)y2 * a.Wc + cx], e0, e1);
   };
   float v;
-  if (x & 1) v = vert(mx) * o + vert(x2) * o;
-  else v = vert(x0) * e0 + vert(mx) * e1 + vert(x2) * e0;
+  if (x & 1) v = expand_odd(vert(mx), vert(x2), o);
+  else v = expand_even(vert(x0), vert(mx), vert(x2), e0, e1);
   f[pix] += v;
 }
 
@@ -480,15 +513,15 @@ __global__ __launch_bounds__(256) void k_expand_add4(ExpandAddArgs a) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int cx = min(max(mx - 1 + k, 0), a.Wc - 1);
-    if (y & 1) v[k] = c[(int64_t)my * a.Wc + cx] * o + c[(int64_t)y2 * a.Wc + cx] * o;
-    else v[k] = c[(int64_t)y0 * a.Wc + cx] * e0 + c[(int64_t)my * a.Wc + cx] * e1 + c[(int64_t)y2 * a.Wc + cx] * e0;
+    if (y & 1) v[k] = expand_odd(c[(int64_t)my * a.Wc + cx], c[(int64_t)y2 * a.Wc + cx], o);
+    else v[k] = expand_even(c[(int64_t)y0 * a.Wc + cx], c[(int64_t)my * a.Wc + cx], c[(int64_t)y2 * a.Wc + cx], e0, e1);
   }
   float4* p = reinterpret_cast<float4*>(f + (int64_t)y * a.W + x);
   float4 t = *p;
-  t.x += v[0] * e0 + v[1] * e1 + v[2] * e0;
-  t.y += v[1] * o + v[2] * o;
-  t.z += v[1] * e0 + v[2] * e1 + v[3] * e0;
-  t.w += v[2] * o + v[3] * o;
+  t.x += expand_even(v[0], v[1], v[2], e0, e1);
+  t.y += expand_odd(v[1], v[2], o);
+  t.z += expand_even(v[1], v[2], v[3], e0, e1);
+  t.w += expand_odd(v[2], v[3], o);
   *p = t;
 }
 

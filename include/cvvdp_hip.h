@@ -19,11 +19,11 @@
  *     helper streams the handle owns).  No other entry point synchronises.
  *   - the core allocates no device MEMORY: the caller provides one workspace buffer of
  *     cvvdp_workspace_bytes() bytes (so torch's caching allocator stays the only allocator).  It does own a few
- *     HIP objects, created lazily on first use and destroyed with the handle: up to three non-blocking helper
- *     streams with their fork / join events -- two for the small pyramid levels of images and short blocks, which
- *     run beside level 0, and an edge stream on which the border strips of a level run beside its border-free
- *     strips (fused levels of W % 4 == 2 frames and of features clips; the edge strips of large ragged frames); the caller's stream waits for them
- *     by event before anything reads the results -- and, while profiling is enabled, timing events.
+ *     HIP objects, created lazily on first use and destroyed with the handle: up to five non-blocking helper
+ *     streams with their fork / join events -- two side streams for the small pyramid levels of images and short blocks (and the levels
+ *     behind the fused ones of large blocks), which run beside the caller's stream, and per stream a level can run on (the caller's, the
+ *     two side streams) one edge stream on which the border strips of that level run beside its border-free strips; the caller's stream
+ *     waits for all of them by event before anything reads the results -- and, while profiling is enabled, timing events.
  *   - scores do not depend on how a clip is cut into blocks or shards (bit for bit), but the band kernels a level
  *     runs on depend on what else is asked for: plain scoring, heat maps and features have their own kernels on the
  *     fused route (k_band4s / _heat / _feat; features keep k_band4f_feat on the border strips) and the debug dump runs

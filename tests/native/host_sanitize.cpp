@@ -103,7 +103,10 @@ void launch_reduce(const ReduceArgs& a, hipStream_t) {
   in_ws(a.in, ((size_t)(a.n_planes - 1) * a.img_cap + a.n_img) * a.H * a.W, "reduce in");       // (level 0 of a clip scored in pieces: a.in points at the piece)
   in_ws(a.out, (size_t)a.n_planes * a.img_cap_out * a.Ho * a.Wo, "reduce out");
 }
-bool reduce2_supported(int H, int W) { return (W % 16 == 0 || W >= 32) && H >= 8; }   // (mirror of pyramid.hip)
+bool reduce_takes_ref_kernel(int H, int W) { return (int64_t)H * W <= kReduceRefPixels || W < 16 || H < 4; }   // (mirror of pyramid.hip)
+bool reduce2_supported(int H, int W) {
+  return (W % 16 == 0 || W >= 32) && H >= 8 && !reduce_takes_ref_kernel(H, W) && !reduce_takes_ref_kernel((H + 1) / 2, (W + 1) / 2);
+}
 void launch_reduce2(const Reduce2Args& a, hipStream_t) {
   ++g_launches; chk_reduce_geom(a.H, a.W, a.H1, a.W1, "reduce2 l+1"); chk_reduce_geom(a.H1, a.W1, a.H2, a.W2, "reduce2 l+2");
   REQUIRE(reduce2_supported(a.H, a.W), "reduce2 launched on %dx%d", a.W, a.H);

@@ -52,6 +52,12 @@ def test_fused_kernel_streams_are_safe_too(tmp_path):
     for s in starts:
         e = next(i for i in range(s, len(text)) if ".end_amdhsa_kernel" in text[i] or text[i].startswith("\t.section"))
         bad, n_loads, n_loops = chk.check_kernel(text[s].split(":")[0], text[s:e])
+        if "k_band4fILi4ELi1EE" in text[s]:
+            # the plain EDGE == 1 instantiation (border strips of the one-wave A/B layout only) has compiler-managed loads since round 6
+            # (band4f.hip, F_SAFE): nothing hand-issued is left in it
+            body = text[s:e]
+            assert sum(1 for i, l in enumerate(body) if i > 0 and "global_load_dword" in l and "ASMSTART" in body[i - 1]) == 0
+            continue
         assert n_loads == 48 and bad == 0, (n_loads, bad)          # eight steps x (four neighbour loads + two row loads)
         assert "\n".join(text[s:e]).count("s_waitcnt vmcnt(2)") >= 8
 

@@ -103,8 +103,9 @@ def check_file(path):
     total_bad = 0
     for s in starts:
         e = next(i for i in range(s, len(text)) if ".end_amdhsa_kernel" in text[i] or text[i].startswith("\t.section"))
-        if "k_band4f_heat" in text[s] or "k_band4f_feat" in text[s]:
-            # the HEAT / FEAT instantiations of k_band4f use ordinary, compiler-tracked loads (band4f.hip, F_SAFE): nothing hand-issued may
+        if "k_band4f_heat" in text[s] or "k_band4f_feat" in text[s] or re.match(r"^_ZN5cvvdp8k_band4fILi\dELi1EE", text[s]):
+            # the HEAT / FEAT instantiations of k_band4f and (round 6) its plain EDGE == 1 instantiation, which only the one-wave A/B layout
+            # runs, use ordinary, compiler-tracked loads (band4f.hip, F_SAFE): nothing hand-issued may
             # be left in them; what the compiler schedules around its own loads (spill reloads included) is its business
             body = text[s:e]
             hand = sum(1 for i, l in enumerate(body) if i > 0 and "global_load_dword" in l and "ASMSTART" in body[i - 1])

@@ -132,22 +132,60 @@ def synth_frame(f, H, W, device, seed_ref=1234, seed_noise=5678):
 
 def cpu_frame_pool(frame_ids, H, W):
     """Iterator over synth_frame(f, H, W, "cpu") for f in frame_ids, made concurrently: ~1 s per 4K frame single-threaded, so
-    several frames at a time (torch releases the GIL), each with a share of the cores (no nested oversubscription).
+    several frames at a time (torch releases the GIL), each with a share of the cores (no nested oversubscription; elementwise
+    torch operators on 25 M samples stop scaling at a handful of threads, so: many workers with four threads each).
     Returns (iterator, pool, torch thread count to restore after pool.shutdown())."""
     import concurrent.futures
     ncpu = os.cpu_count() or 1
-    workers = max(1, min(8, ncpu // 4))
+    workers = max(1, min(32, ncpu // 4))
     threads_before = torch.get_num_threads()
     torch.set_num_threads(max(1, min(threads_before, ncpu // workers)))
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers)
     return pool.map(lambda f: synth_frame(f, H, W, "cpu"), frame_ids), pool, threads_before
 
 
+# Frames of the CPU generator already made in this process, on the device: (H, W) -> dict(test, ref: uint8 [3, n, H, W]; sum_t, sum_r: per-frame
+# checksums).  Off in bench runs (a clip is made once); tests/conftest.py turns it on for the GPU session, where a dozen tests score
+# prefixes of the same three clips (4K x 256, 8K x 80, 1080p x 64) against fixtures of the real reference: 900 4K frames at ~0.25 s
+# each were a fifth of the suite's time.
+CACHE_CPU_FRAMES = False
+_cpu_frames = {}
+
+
+def cpu_generated_frames(H, W, lo, hi, device):
+    """Frames lo .. hi-1 of the CPU generator (the one the reference fixtures were made with) as uint8 device tensors [3, hi-lo, H, W]
+    (test, ref) and their checksums (sums of all codes; taken on the device: the int64 conversion of 100 M samples on the host cost
+    as much as making the frame)."""
+    key = (H, W, str(device))
+    c = _cpu_frames.get(key) if CACHE_CPU_FRAMES else None
+    have = 0 if c is None else c["test"].shape[1]
+    start = have if (c is not None and lo <= have) else lo          # extend the cached prefix, or make just this range
+    if c is None or hi > have:
+        n_new = hi - start
+        t = torch.empty((3, n_new, H, W), dtype=torch.uint8, device=device)
+        r = torch.empty((3, n_new, H, W), dtype=torch.uint8, device=device)
+        made, pool, threads_before = cpu_frame_pool(range(start, hi), H, W)
+        for k, (a, b) in enumerate(made):
+            t[:, k], r[:, k] = a.to(device), b.to(device)
+        pool.shutdown(wait=True)
+        torch.set_num_threads(threads_before)
+        st, sr = t.sum(dim=(0, 2, 3), dtype=torch.int64).tolist(), r.sum(dim=(0, 2, 3), dtype=torch.int64).tolist()
+        if c is not None and start == have:
+            c = {"test": torch.cat([c["test"], t], dim=1), "ref": torch.cat([c["ref"], r], dim=1), "sum_t": c["sum_t"] + st, "sum_r": c["sum_r"] + sr, "first": 0}
+        else:
+            c = {"test": t, "ref": r, "sum_t": st, "sum_r": sr, "first": start}
+        if CACHE_CPU_FRAMES and c["first"] == 0:
+            _cpu_frames[key] = c
+    a, b = lo - c["first"], hi - c["first"]
+    return c["test"][:, a:b], c["ref"][:, a:b], sum(c["sum_t"][a:b]), sum(c["sum_r"][a:b])
+
+
 class ResidentClip:
     """video source whose frames [lo, hi) live in HBM; implements the raw-block fast path.  gen="cpu": the frames are made
     with the CPU generator (the one the reference fixtures were made with) and uploaded; "gpu": made on the device (a
     different random stream, much faster for long clips).  pq_range: map the codes into [0.10, 0.75] (about 0.3 .. 1000
-    cd/m^2 on a PQ display)."""
+    cd/m^2 on a PQ display).  checksum_test / checksum_ref (gen="cpu"): sums of the generator's codes (before the PQ-range
+    map), what the fixtures record."""
 
     def __init__(self, n_total, lo, hi, H, W, fps, dtype, device, gen="gpu", pq_range=False):
         self.n_total, self.lo, self.hi, self.H, self.W, self.fps = n_total, lo, hi, H, W, fps
@@ -157,24 +195,18 @@ class ResidentClip:
         self.test = torch.empty((1, 3, hi - lo, H, W), dtype=tdt, device=device)
         self.ref = torch.empty((1, 3, hi - lo, H, W), dtype=tdt, device=device)
         self.checksum_test = self.checksum_ref = 0
-        made = None
+        src = None
         if gen == "cpu":
-            made, pool, threads_before = cpu_frame_pool(range(lo, hi), H, W)
+            src_t, src_r, self.checksum_test, self.checksum_ref = cpu_generated_frames(H, W, lo, hi, device)
+            src = (src_t, src_r)
         for f in range(lo, hi):
-            t, r = next(made) if made is not None else synth_frame(f, H, W, device)
-            if gen == "cpu":
-                self.checksum_test += int(t.to(torch.int64).sum())
-                self.checksum_ref += int(r.to(torch.int64).sum())
-                t, r = t.to(device), r.to(device)
+            t, r = (src[0][:, f - lo], src[1][:, f - lo]) if src is not None else synth_frame(f, H, W, device)
             if pq_range:
                 t, r = ((x.float() * 0.65 + 0.10 * 255).round().to(torch.uint8) for x in (t, r))
             if dtype == "f32":
                 t, r = t.float() / 255, r.float() / 255
             self.test[0, :, f - lo] = t
             self.ref[0, :, f - lo] = r
-        if made is not None:
-            pool.shutdown(wait=True)
-            torch.set_num_threads(threads_before)
 
     def get_video_size(self):
         return (self.H, self.W, self.n_total)

@@ -243,6 +243,8 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
   const bool use_lut = stage_eotf_table<DT>(a.dm, s_tab);
   static_assert(FL >= 3 && 2 * (FL - 1) <= CVVDP_ROT_NEW, "window = one 16- or 32-wide register vector + the newest frame in a scalar slot");
   typedef float v16f __attribute__((ext_vector_type(FL <= 17 ? 16 : 32)));
+  typedef float v2f_ __attribute__((ext_vector_type(2)));
+  static_assert((FL - 1) % 2 == 0, "the older frames are summed in slot pairs");
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= a.P) return;
   const int b = blockIdx.y, side = blockIdx.z;
@@ -333,8 +335,13 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
     _Pragma("unroll") for (int c = 0; c < 4; ++c) { /* Y-sust, RG, YV, Y-trans (plane 0 again), cvvdp_metric.py:554-560 */ \
       const int p = (c == 3) ? 0 : c;                                                                            \
       const float* t = tb + c * CVVDP_ROT_TAPS;                                                                  \
-      float acc = 0.0f;                                                                                          \
-      _Pragma("unroll") for (int s = 0; s < M; ++s) acc += wlo[p][s] * t[s];                                     \
+      /* Round 6: the M older frames as M/2 PACKED multiply-adds (v_pk_fma_f32: slots 2j, 2j+1 are an aligned register pair of the  */ \
+      /* window vector, their taps an SGPR pair) -- 62 + 8 instead of 124 FMAs per frame at 31 taps, where this kernel is VALU-bound. */ \
+      /* Two interleaved partial sums (even slots, odd slots), added at the end: the order is a function of the slots, i.e. of the     */ \
+      /* frames' CLIP indices, so results still do not depend on how the clip is cut.                                                 */ \
+      v2f_ acc2 = {0.0f, 0.0f};                                                                                  \
+      _Pragma("unroll") for (int s = 0; s < M; s += 2) acc2 += v2f_{wlo[p][s], wlo[p][s + 1]} * v2f_{t[s], t[s + 1]}; \
+      float acc = acc2.x + acc2.y;                                                                               \
       acc += whi[p] * a.taps_rot[c * CVVDP_ROT_TAPS + CVVDP_ROT_NEW];                                            \
       CVVDP_FIR_STORE(acc, &out[(int64_t)(2 * c + side) * a.o_plane + (int64_t)(FI) * o_item]);                \
     }                                                                                                            \

@@ -669,10 +669,14 @@ class cvvdp(vq_metric):
         heatmap = None
         hm_ch = 1 if self.heatmap == "raw" else 3
         copy_stream = None
-        stage, pending_sink = None, []
+        stage, pending_sink, stage_next = None, [], [0]
         if self.do_heatmap and heatmap_sink is not None:
-            # Streaming: two page-locked staging buffers of one block each; block k is handed to the sink while
-            # the kernels of block k+1 run.  Host memory is bounded by 2 blocks whatever the clip length.
+            # Streaming: a ring of page-locked staging buffers of one piece each; piece k is handed to the sink while
+            # the kernels of the pieces after it run.  Host memory is bounded by `heatmap_stage_buffers` pieces whatever the clip length.
+            # Four buffers since round 6 (two before): the kernels of an 8K piece take 21 ms and its 8-bit frames 31 ms of the PCIe link,
+            # so the link is the bound -- and with two buffers it ran dry at every temporal block boundary, where the next piece is
+            # 38 ms away (the block's temporal kernel + the piece's bands) while only one piece was queued: 8K x 256 took 564 ms for 490 ms
+            # of copying.  With a backlog of up to three pieces the copy engine always has work.
             # A sink that writes 8-bit frames anyway (PNG, ffmpeg) sets `wants_uint8`: the conversion the reference's writers do on
             # the host is then done by the heat-map kernel, and 3 instead of 6 bytes per pixel cross PCIe
             nb_max = 1 if is_image else (clip.score_frames if clip.defer_bands else clip.block_frames)
@@ -684,8 +688,12 @@ class cvvdp(vq_metric):
             stage = getattr(self, "_hm_stage", None)
             if sink_dev:
                 stage = "device"
-            elif stage is None or stage == "device" or stage[0].numel() < hm_ch * nb_max * height * width:       # (fp16 elements: enough for either format)
-                stage = self._hm_stage = [torch.empty(hm_ch * nb_max * height * width, dtype=torch.float16, device="cpu", pin_memory=True) for _ in range(2)]
+            else:
+                n_stage = max(2, int(getattr(self, "heatmap_stage_buffers", 4)))
+                need = hm_ch * nb_max * height * width * (1 if sink_u8 else 2)                               # bytes per piece
+                if stage is None or stage == "device" or len(stage) != n_stage or stage[0].numel() < need:
+                    self._hm_stage = None                                                                   # (unpin the old ring first)
+                    stage = self._hm_stage = [torch.empty(need, dtype=torch.uint8, device="cpu", pin_memory=True) for _ in range(n_stage)]
             if not sink_dev:
                 copy_stream = getattr(self, "_hm_stream", None) or torch.cuda.Stream(self.device)
                 self._hm_stream = copy_stream
@@ -727,19 +735,21 @@ class cvvdp(vq_metric):
                 heatmap_sink(first + ff, buf if sink_u8 else buf.view(1, hm_ch, n, height, width))
                 return
             if stage is not None:
-                flush_sink(keep=1)                         # the buffer about to be overwritten has been consumed
-                dst = stage[1] if (pending_sink and pending_sink[0][3] == 0) else stage[0]
+                flush_sink(keep=len(stage) - 1)            # the buffer about to be overwritten has been consumed
+                slot = stage_next[0]
+                stage_next[0] = (slot + 1) % len(stage)
+                dst = stage[slot]
                 if sink_u8:
-                    view = dst.view(torch.uint8)[:hm_ch * n * height * width].view(n, height, width, hm_ch)
+                    view = dst[:hm_ch * n * height * width].view(n, height, width, hm_ch)
                 else:
-                    view = dst[:hm_ch * n * height * width].view(1, hm_ch, n, height, width)
+                    view = dst[:2 * hm_ch * n * height * width].view(torch.float16).view(1, hm_ch, n, height, width)
                 copy_stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(copy_stream):
                     (view if sink_u8 else view[0]).copy_(buf, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(copy_stream)
                 buf.record_stream(copy_stream)
-                pending_sink.append((ev, first + ff, view, 0 if dst is stage[0] else 1))
+                pending_sink.append((ev, first + ff, view, slot))
                 return
             # one copy per colour plane: heatmap[0, ch, ff:ff+n] is contiguous on the host, the [3, n, H, W] slice of a
             # longer clip is not (a strided D2H copy falls off the DMA path: 6x slower end to end)
@@ -802,8 +812,16 @@ class cvvdp(vq_metric):
                         fetch_features(ff - first, n)
                     del t, r
             blocks = []
-            for ff in (range(first, first + count, nb) if not prefiltered else ()):
-                n = min(nb, first + count - ff)
+            # Heat maps streamed to the host from a resident clip: the link is the bound, and its first byte can only leave after the first
+            # temporal block's FIR + the first piece's bands -- so the first temporal block is ONE piece long (8K: the D2H stream starts
+            # 13 ms earlier; results do not depend on the cut, bit for bit)
+            head = int(clip.score_frames) if (isinstance(stage, list) and clip.defer_bands and clip.raw_halo and 0 < clip.score_frames < nb) else nb
+            cuts, ff = [], first
+            while not prefiltered and ff < first + count:
+                n = min(head if ff == first else nb, first + count - ff)
+                cuts.append((ff, n))
+                ff += n
+            for ff, n in cuts:
                 if ff == first or clip.raw_halo:
                     # first block of the clip / shard, and every block of a device-resident clip: the fl-1 window
                     # positions before frame ff are real predecessor / halo frames or temporal padding; all of them

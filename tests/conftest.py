@@ -16,6 +16,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _share_cpu_generated_frames():
+    """GPU session: the frames bench.py's CPU generator makes (the ones the reference fixtures were made from) are kept on the device
+    once made -- a dozen tests score prefixes of the same 4K, 8K and 1080p clips (bench.cpu_generated_frames)."""
+    import torch
+    if torch.cuda.is_available():
+        import bench
+        bench.CACHE_CPU_FRAMES = True
+    yield
+
+
+@pytest.fixture(autouse=True)
+def _return_unused_device_memory():
+    """After a test that left tens of gigabytes in torch's caching allocator (8K clips, 100 GB workspaces) the blocks go back to the
+    driver: the next big test's workspace is ONE allocation, and a fragmented cache cannot serve it however much of it is unused."""
+    yield
+    import torch
+    if torch.cuda.is_available() and torch.cuda.memory_reserved() - torch.cuda.memory_allocated() > (16 << 30):
+        torch.cuda.empty_cache()
+
+
 def _names(pattern):
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN, pattern)))
 

@@ -13,7 +13,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RUNS = 5
+RUNS = 3          # (round 2's hang showed in 3 of 5 runs; since the lock-step spin-up it has never shown in hundreds)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -23,13 +23,13 @@ def _torch_is_paged_in():
     subprocess.run([sys.executable, "-c", "import torch, torch.distributed"], check=True, timeout=900)
 
 
-def _bench_two_ranks(extra, port):
+def _bench_two_ranks(extra, port, world=2, timeout=120):
     env = dict(os.environ, CVVDP_BENCH_BACKEND="gloo", CVVDP_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1",
                HSA_ENABLE_IPC_MODE_LEGACY="0", CVVDP_BENCH_SPINUP_S="0.5")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
            "--cpu-frames", "0"] + extra
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -47,6 +47,23 @@ def test_two_rank_bench_prints_its_line_every_time(workload, extra, frames_total
         assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["config"]["frames_total"] == frames_total
         assert d["value"] > 0 and 0 < d["jod"] <= 10
         assert d["spinup_steps"] >= 1
+
+
+@pytest.mark.parametrize("workload,extra,frames_total", [
+    ("4k1024", [], 1024),                                                                       # configs[3] at its full length: 128 frames per rank
+    ("8k256pq", ["--frames", "128", "--block-frames", "8", "--heatmap-sink", "device"], 128),   # configs[4]'s path (PQ, heat map, distogram), shortened: eight ranks share ONE GPU's memory here
+])
+def test_eight_rank_dry_run_explains_itself(workload, extra, frames_total):
+    """the line the driver's first 8-GPU run will print, dry-run with eight ranks on the one GPU of the box (gloo):
+    eight per-rank times (not only their MAX), the step's only collective timed on its own, the halo frames every rank reads."""
+    d = _bench_two_ranks(["--workload", workload] + extra, 30300 + (os.getpid() % 1500), world=8, timeout=600)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["frames_total"] == frames_total
+    assert len(d["per_rank_ms"]) == 8 and all(t > 0 for t in d["per_rank_ms"]) and d["config"]["per_rank_ms"] == d["per_rank_ms"]
+    assert max(d["per_rank_ms"]) <= d["ms_per_step"] * 1.001                  # the value is priced on the barrier-to-barrier MAX
+    col = d["config"]["collectives"]
+    assert col["world"] == 8 and col["halo_frames_per_rank"] == [0] + [16] * 7 and col["allgather_us"] > 0
+    assert [r["rank"] for r in col["ranks_seen"]] == list(range(8)) and col["distinct_devices"] == 1      # (and says so: the ranks share a GPU)
+    assert d["value"] > 0 and 0 < d["jod"] <= 10
 
 
 def test_rccl_collectives_run_with_one_rank():

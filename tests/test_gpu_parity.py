@@ -548,6 +548,89 @@ def test_configs4_clip_at_full_length_first_80_frames_against_reference():
     torch.cuda.empty_cache()
 
 
+def test_configs4_as_stated_256_frames_with_heat_map_and_distogram():
+    """configs[4] AS BASELINE.json STATES IT -- 7680x4320, PQ, 256 frames, supra-threshold heat map + distogram -- on the clip bench.py
+    --workload 8k256pq times (codes in the PQ range), the heat-map frames consumed on the GPU in pieces of a long temporal block
+    (VERDICT r5 next #3).  What the real reference says about this clip:
+      * Q_per_ch of frames 0..79      tests/golden/deep_8k_pq_80f.npz            (oracle/make_goldens_8k80.py)
+      * heat-map frames 0, 8, 16, the per-frame means of frames 0..16 and the distogram arrays of the 17-frame prefix
+                                      tests/golden/deep_8k_pqrange_heat_17f.npz  (oracle/make_goldens_8k17_pqrange.py)
+    (the temporal filter is causal and the tone curve per frame: a prefix's outputs are the long clip's).  And the same bits whatever
+    the cut: 16- against 32-frame pieces, and a shorter temporal block."""
+    import bench
+    import colorvideovdp_amd as cv
+    g80, g17 = load_golden("deep_8k_pq_80f"), load_golden("deep_8k_pqrange_heat_17f")
+    W, H, F80, F17, F = int(g80["width"]), int(g80["height"]), int(g80["frames"]), int(g17["frames"]), 256
+    fps, disp = float(g80["fps"]), str(g80["display"])
+    # frames 0..79 from the CPU generator the fixtures were made with (shared with the other 8K tests), 80..255 from the device generator
+    clip = bench.ResidentClip(F, 0, F, H, W, fps, "u8", torch.device("cuda"), gen="gpu", pq_range=True)
+    head = bench.ResidentClip(F80, 0, F80, H, W, fps, "u8", torch.device("cuda"), gen="cpu", pq_range=True)
+    clip.test[:, :, :F80], clip.ref[:, :, :F80] = head.test, head.ref
+    del head
+    cs = lambda n: (int(clip.test[:, :, :n].sum(dtype=torch.int64)), int(clip.ref[:, :, :n].sum(dtype=torch.int64)))     # noqa: E731
+    if cs(F80) != (int(g80["checksum_test"]), int(g80["checksum_ref"])) or cs(F17) != (int(g17["checksum_test"]), int(g17["checksum_ref"])):
+        pytest.fail("this torch build's CPU generator does not reproduce the fixtures' synthetic frames (checksum mismatch)")
+    keep = [int(k) for k in g17["heatmap_frames"]]
+
+    class Sink:                          # what a consumer on the GPU sees: every piece as a device tensor
+        wants_device, wants_uint8 = True, False
+
+        def __init__(self):
+            self.firsts, self.kept, self.means = [], {}, []
+
+        def __call__(self, first, frames):
+            assert frames.is_cuda and frames.dtype == torch.float16 and tuple(frames.shape[:2]) == (1, 3) and tuple(frames.shape[3:]) == (H, W)
+            self.firsts.append((first, frames.shape[2]))
+            self.means.append(frames[0].float().mean(dim=(0, 2, 3)))
+            for k in keep:
+                if first <= k < first + frames.shape[2]:
+                    self.kept[k] = frames[0, :, k - first, ::16, ::16].clone()
+
+    runs = []
+    for score_frames, block in ((None, None), (32, None), (None, 40)):
+        m = cv.cvvdp(display_name=disp, heatmap=str(g17["heatmap_mode"]), block_frames=block)
+        if score_frames is not None:
+            m.score_frames = score_frames
+        sink = Sink()
+        jod, stats = m.predict_video_source(clip, heatmap_sink=sink)
+        assert "heatmap" not in stats and stats["Q_per_ch"].shape[2] == F
+        pos = 0
+        for first, n in sink.firsts:                                       # the pieces tile the clip in order
+            assert first == pos
+            pos += n
+        assert pos == F and len(sink.firsts) >= F // 32
+        assert m.last_block_frames < F                                     # more than one temporal block
+        runs.append((stats["Q_per_ch"], torch.stack([sink.kept[k] for k in keep], dim=1).cpu(), torch.cat(sink.means).cpu().numpy(), float(jod),
+                     {k: v for k, v in stats.items() if k != "heatmap"}))
+        del m, sink                                                        # (one metric's workspace at a time: tens of gigabytes at 8K)
+        torch.cuda.empty_cache()
+    q, hm_keep, means, jod, stats = runs[0]
+    m = cv.cvvdp(display_name=disp)                                        # (pooling / distogram arithmetic only: no workspace)
+    # ---- the reference: scores of frames 0..79, heat-map frames 0 / 8 / 16, the means of frames 0..16, the distogram of the 17-frame prefix
+    np.testing.assert_allclose(q[:, :, :F80], g80["Q_per_ch"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(q[:, :, :F17], g17["Q_per_ch"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(stats["rho_band"], g80["rho_band"], rtol=1e-12)
+    assert abs(float(m.do_pooling_and_jods(torch.as_tensor(q[:, :, :F80], device=m.device))) - float(g80["jod"])) <= JOD_TOL
+    assert abs(float(m.do_pooling_and_jods(torch.as_tensor(q[:, :, :F17], device=m.device))) - float(g17["jod"])) <= JOD_TOL
+    _check_heatmap(hm_keep, g17["heatmap_ds"], "deep_8k_pqrange_heat_17f")
+    np.testing.assert_allclose(means[:F17], g17["heatmap_frame_means"], atol=2e-4)
+    st17 = dict(stats, Q_per_ch=q[:, :, :F17], N_frames=F17)
+    for jm, key in ((None, "disto_auto"), (10, "disto_10")):               # cvvdp_metric.py:1160-1192: what imshow is handed
+        panels, _ = m.distogram_data(st17, jod_max=jm)
+        assert panels.shape == g17[key].shape
+        np.testing.assert_allclose(panels, g17[key], rtol=5e-4, atol=2e-6)
+    panels, _ = m.distogram_data(stats, jod_max=10)                         # ... and the 256-frame distogram exists and is finite
+    assert panels.shape[-1] == F and np.isfinite(panels).all()
+    # ---- cut differently: the same bits (scores, heat-map frames, means) and the same JOD
+    for q2, hm2, means2, jod2, _ in runs[1:]:
+        np.testing.assert_array_equal(q2, q)
+        assert torch.equal(hm2, hm_keep)
+        np.testing.assert_array_equal(means2, means)
+        assert jod2 == jod
+    del clip, runs
+    torch.cuda.empty_cache()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # host-side outputs and the rest of the class API against the real reference (oracle/make_goldens_outputs.py)
 def _outputs():

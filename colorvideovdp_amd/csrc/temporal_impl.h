@@ -265,7 +265,11 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
   v16f wlo[3];
   float whi[3];
   int sA = ((a.abs_first % M) + M) % M;               // A mod M for the frame about to be processed
+#ifdef CVVDP_FIR_DIAG_PF   /* timing variant: prefetch depth */
+  constexpr int PF = CVVDP_FIR_DIAG_PF;
+#else
   constexpr int PF = is_yuv(DT) ? 2 : 4;   // nine integer samples per prefetched Y'CbCr pixel: keep the VGPR count at 5 waves/SIMD
+#endif
   // A frame-range shard starts with M real halo frames that sit right before its first frame (hist_src = a run of raw
   // frames): they are pushed through the same pipelined loop as the scored frames, minus the FIR and the stores,
   // instead of one exposed memory round trip per entry.
@@ -324,6 +328,23 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
 #else
 #define CVVDP_FIR_STORE(v, p) __builtin_nontemporal_store(v, p)
 #endif
+#if defined(CVVDP_FIR_DIAG_CHAINS2)   /* timing variant (tools/build_variant.sh): two independent chains per channel */
+#define CVVDP_FIR_SUM_PAIRS                                                                                      \
+      v2f_ acc2b = {0.0f, 0.0f};                                                                                 \
+      _Pragma("unroll") for (int s = 0; s < M; s += 4) {                                                         \
+        acc2 += v2f_{wlo[p][s], wlo[p][s + 1]} * v2f_{t[s], t[s + 1]};                                           \
+        if (s + 2 < M) acc2b += v2f_{wlo[p][s + 2], wlo[p][s + 3]} * v2f_{t[s + 2], t[s + 3]};                   \
+      }                                                                                                          \
+      acc2 += acc2b;
+#elif defined(CVVDP_FIR_DIAG_SCALAR)  /* timing variant: round 5's scalar multiply-adds */
+#define CVVDP_FIR_SUM_PAIRS                                                                                      \
+      float accs = 0.0f;                                                                                         \
+      _Pragma("unroll") for (int s = 0; s < M; ++s) accs += wlo[p][s] * t[s];                                    \
+      acc2.x = accs;
+#else
+#define CVVDP_FIR_SUM_PAIRS                                                                                      \
+      _Pragma("unroll") for (int s = 0; s < M; s += 2) acc2 += v2f_{wlo[p][s], wlo[p][s + 1]} * v2f_{t[s], t[s + 1]};
+#endif
 #define CVVDP_FIR_FRAME(FI, Q)                                                                                   \
   {                                                                                                              \
     float d[3][1];                                                                                               \
@@ -340,7 +361,7 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
       /* Two interleaved partial sums (even slots, odd slots), added at the end: the order is a function of the slots, i.e. of the     */ \
       /* frames' CLIP indices, so results still do not depend on how the clip is cut.                                                 */ \
       v2f_ acc2 = {0.0f, 0.0f};                                                                                  \
-      _Pragma("unroll") for (int s = 0; s < M; s += 2) acc2 += v2f_{wlo[p][s], wlo[p][s + 1]} * v2f_{t[s], t[s + 1]}; \
+      CVVDP_FIR_SUM_PAIRS                                                                                        \
       float acc = acc2.x + acc2.y;                                                                               \
       acc += whi[p] * a.taps_rot[c * CVVDP_ROT_TAPS + CVVDP_ROT_NEW];                                            \
       CVVDP_FIR_STORE(acc, &out[(int64_t)(2 * c + side) * a.o_plane + (int64_t)(FI) * o_item]);                \
@@ -356,6 +377,7 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
   for (int u = 0; u + 1 < PF; ++u)                    // remainder: slots 0.. hold frames fi.. in order
     if (fi + u < a.n_frames) CVVDP_FIR_FRAME(fi + u, u)
 #undef CVVDP_FIR_FRAME
+#undef CVVDP_FIR_SUM_PAIRS
   // ---- epilogue: the last M frames in time order = window positions 1..M of the last frame's window: position k < M
   // sits in slot (A_last + k) mod M = (sA - 1 + k) mod M (sA is already A_last + 1), position M is whi
   if (a.write_hist) {

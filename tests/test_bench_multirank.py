@@ -30,10 +30,16 @@ def _bench_two_ranks(extra, port, world=2, timeout=120):
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
            "--cpu-frames", "0"] + extra
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert p.returncode == 0, _what_the_ranks_said(p)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     return json.loads(lines[0])
+
+
+def _what_the_ranks_said(p):
+    """The ranks' own error lines first (the launcher's summary of who got which signal fills the tail of stderr)."""
+    own = [l for l in (p.stdout + "\n" + p.stderr).splitlines() if ("Error" in l or "error" in l or "bench.py:" in l) and "elastic" not in l and "SIGTERM" not in l]
+    return "\n".join(own[-40:]) + "\n---- tail\n" + p.stderr[-1500:]
 
 
 @pytest.mark.parametrize("workload,extra,frames_total,scaling", [
@@ -50,7 +56,7 @@ def test_two_rank_bench_prints_its_line_every_time(workload, extra, frames_total
 
 
 @pytest.mark.parametrize("workload,extra,frames_total", [
-    ("4k1024", [], 1024),                                                                       # configs[3] at its full length: 128 frames per rank
+    ("4k1024", ["--block-frames", "32"], 1024),                                                 # configs[3] at its full length: 128 frames per rank (short blocks: eight ranks share ONE GPU's memory here, the default policy sizes blocks for a GPU of one's own)
     ("8k256pq", ["--frames", "128", "--block-frames", "8", "--heatmap-sink", "device"], 128),   # configs[4]'s path (PQ, heat map, distogram), shortened: eight ranks share ONE GPU's memory here
 ])
 def test_eight_rank_dry_run_explains_itself(workload, extra, frames_total):

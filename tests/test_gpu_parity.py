@@ -986,7 +986,7 @@ def test_large_ragged_frames_split_off_their_edge_strips():
     m2.fuse_mode = 2
     _, s_unfused = m2.predict_video_source(long)
     assert m2.fused_levels == 0
-    np.testing.assert_allclose(s_long["Q_per_ch"], s_unfused["Q_per_ch"], rtol=5e-5, atol=5e-7)
+    np.testing.assert_allclose(s_long["Q_per_ch"], s_unfused["Q_per_ch"], rtol=2e-4, atol=2e-6)      # (two routes, two roundings: the generic tolerance)
 
 
 def test_8k_pq_full_temporal_window_heatmap_and_distogram_against_reference():
@@ -1170,7 +1170,10 @@ def test_fused_reduce_band_kernels(W, H, F, fps, disp):
     for l, (a, b) in enumerate(zip(p1, p2)):
         np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-6 * max(1.0, float(np.abs(b).max())), err_msg=f"pyramid level {l}")
     assert not np.array_equal(p1[1], p2[1]) or W * H < 0      # (the two routes do round differently: the fused one did run)
-    np.testing.assert_allclose(q1, q2, rtol=5e-5, atol=5e-7)
+    # (since round 6 the unfused route reduces levels <= 128 x 128 in the reference's operation order while the fused kernels -- forced onto
+    # these small frames by the test hook -- keep the horizontal pass first: at a coarse band of a few dozen pixels the two now differ by
+    # up to the generic tolerance, 1.1e-4 observed; both are held to the oracle below)
+    np.testing.assert_allclose(q1, q2, rtol=2e-4, atol=2e-6)
     assert abs(j1 - float(ojod)) <= JOD_TOL and abs(j2 - float(ojod)) <= JOD_TOL
     np.testing.assert_allclose(q1, ostats["Q_per_ch"], rtol=2e-4, atol=2e-6)
 
@@ -1204,7 +1207,7 @@ def test_fused_kernels_with_a_batch_and_other_sample_formats(dt):
         np.testing.assert_allclose(stats["Q_per_ch"], ostats["Q_per_ch"], rtol=2e-4, atol=2e-6)
         qs[mode] = stats["Q_per_ch"]
     assert qs[1].shape[0] == 2
-    np.testing.assert_allclose(qs[1], qs[2], rtol=5e-5, atol=5e-7)
+    np.testing.assert_allclose(qs[1], qs[2], rtol=2e-4, atol=2e-6)
 
 
 def test_fused_route_is_a_property_of_the_clip():
@@ -1372,7 +1375,7 @@ def test_fused_band_kernels_write_the_heat_map_bands(W, H, F, fps, disp, mode):
     dl = (runs["split"][2].float() - runs["one_wave"][2].float()).abs()
     assert float(dl.max()) <= 1e-3 and float((dl > 0).float().mean()) < 1e-3      # (fp16 codes; the last-bit caveat of the test above)
     assert abs(runs["split"][0] - runs["unfused"][0]) < 1e-4
-    np.testing.assert_allclose(runs["split"][1], runs["unfused"][1], rtol=5e-5, atol=5e-7)       # (test_fused_reduce_band_kernels' bound)
+    np.testing.assert_allclose(runs["split"][1], runs["unfused"][1], rtol=2e-4, atol=2e-6)       # (test_fused_reduce_band_kernels' bound)
     d = (runs["split"][2].float() - runs["unfused"][2].float()).abs()
     # the two routes round the pyramid differently in the last bit; the map is fp16: a handful of pixels land on a neighbouring code
     assert float(d.max()) <= 2e-3 and float((d > 0).float().mean()) < 0.02, (float(d.max()), float((d > 0).float().mean()))

@@ -579,6 +579,16 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a, S4Lds<HEAT, FEAT>
     // vertical 13-tap blur of the window -> Mq = (blur + eps)^q -> s_q; then the weights rotate
     auto vblur = [&](int yc) {
       if (interior && yc >= ys) {
+#ifdef S_DIAG_VB4      // timing variant: four dependent chains instead of two (results differ in the last bit)
+        v2f va = kEps, vb = kEps, va1 = 0.0f, vb1 = 0.0f;
+#pragma unroll
+        for (int sdx = 0; sdx < S_BW; ++sdx) {
+          const v2f wa = {winA[2 * sdx], winA[2 * sdx + 1]}, wb = {winB[2 * sdx], winB[2 * sdx + 1]};
+          const v2f ww = {wr[sdx], wr[sdx]};
+          if (sdx & 1) { va1 += ww * wa; vb1 += ww * wb; } else { va += ww * wa; vb += ww * wb; }
+        }
+        va += va1; vb += vb1;
+#else
         v2f va = kEps, vb = kEps;
 #pragma unroll
         for (int sdx = 0; sdx < S_BW; ++sdx) {
@@ -586,6 +596,7 @@ __device__ __forceinline__ void band4s_body(const BandArgs& a, S4Lds<HEAT, FEAT>
           const v2f ww = {wr[sdx], wr[sdx]};
           va += ww * wa; vb += ww * wb;
         }
+#endif
         const float v[4] = {va.x, va.y, vb.x, vb.y};
         float Mq[4];
 #pragma unroll
@@ -820,7 +831,7 @@ int tu_flags_band4s() {
   f |= CVVDP_BUILD_SAFE_LOADS;
 #endif
 #if defined(S_DIAG_NOBAR) || defined(S_DIAG_BACK_ONLY) || defined(S_DIAG_FRONT_ONLY) || defined(S_DIAG_NO_STORE) || defined(S_DIAG_PLAIN_STORE) || \
-    defined(S_DIAG_NO_NB) || defined(S_DIAG_NO_SG) || defined(S_DIAG_EDGE_RING) || defined(S_DIAG_NO_LUM) || defined(S_PRIO_FRONT) || defined(S_PRIO_BACK) || CVVDP_BAND4S_RING != 8
+    defined(S_DIAG_NO_NB) || defined(S_DIAG_NO_SG) || defined(S_DIAG_EDGE_RING) || defined(S_DIAG_NO_LUM) || defined(S_DIAG_VB4) || defined(S_PRIO_FRONT) || defined(S_PRIO_BACK) || CVVDP_BAND4S_RING != 8
   f |= CVVDP_BUILD_DIAG;
 #endif
   return f;

@@ -328,22 +328,26 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
 #else
 #define CVVDP_FIR_STORE(v, p) __builtin_nontemporal_store(v, p)
 #endif
-#if defined(CVVDP_FIR_DIAG_CHAINS2)   /* timing variant (tools/build_variant.sh): two independent chains per channel */
-#define CVVDP_FIR_SUM_PAIRS                                                                                      \
-      v2f_ acc2b = {0.0f, 0.0f};                                                                                 \
-      _Pragma("unroll") for (int s = 0; s < M; s += 4) {                                                         \
-        acc2 += v2f_{wlo[p][s], wlo[p][s + 1]} * v2f_{t[s], t[s + 1]};                                           \
-        if (s + 2 < M) acc2b += v2f_{wlo[p][s + 2], wlo[p][s + 3]} * v2f_{t[s + 2], t[s + 3]};                   \
-      }                                                                                                          \
-      acc2 += acc2b;
-#elif defined(CVVDP_FIR_DIAG_SCALAR)  /* timing variant: round 5's scalar multiply-adds */
+#ifndef CVVDP_FIR_CHAINS
+#define CVVDP_FIR_CHAINS 2            /* independent accumulator pairs per channel (timing variants: tools/build_variant.sh -DCVVDP_FIR_CHAINS=n) */
+#endif
+#if defined(CVVDP_FIR_DIAG_SCALAR)  /* timing variant: round 5's scalar multiply-adds, one dependent chain of M */
 #define CVVDP_FIR_SUM_PAIRS                                                                                      \
       float accs = 0.0f;                                                                                         \
       _Pragma("unroll") for (int s = 0; s < M; ++s) accs += wlo[p][s] * t[s];                                    \
       acc2.x = accs;
 #else
+/* slot pair j = (2j, 2j+1) goes to chain j mod CHAINS; the chains are added pairwise at the end.  One chain of M/2 dependent packed FMAs   */
+/* per channel left the kernel LATENCY-bound (round 6 A/B, profiles/r06_ab_fir_chains.txt: 60 fps 5.94 -> 5.24 ms with two chains at     */
+/* unchanged instruction count -- it had been taken for HBM-bound at 5.1 TB/s since round 4).  The order is a function of the slots, i.e. of */
+/* the frames' CLIP indices: results still do not depend on how the clip is cut.                                                            */
 #define CVVDP_FIR_SUM_PAIRS                                                                                      \
-      _Pragma("unroll") for (int s = 0; s < M; s += 2) acc2 += v2f_{wlo[p][s], wlo[p][s + 1]} * v2f_{t[s], t[s + 1]};
+      v2f_ ch_[CVVDP_FIR_CHAINS];                                                                                \
+      _Pragma("unroll") for (int q = 0; q < CVVDP_FIR_CHAINS; ++q) ch_[q] = v2f_{0.0f, 0.0f};                    \
+      _Pragma("unroll") for (int s = 0; s < M; s += 2) ch_[(s / 2) % CVVDP_FIR_CHAINS] += v2f_{wlo[p][s], wlo[p][s + 1]} * v2f_{t[s], t[s + 1]}; \
+      _Pragma("unroll") for (int w = 1; w < CVVDP_FIR_CHAINS; w *= 2)                                            \
+        _Pragma("unroll") for (int q = 0; q + w < CVVDP_FIR_CHAINS; q += 2 * w) ch_[q] += ch_[q + w];            \
+      acc2 = ch_[0];
 #endif
 #define CVVDP_FIR_FRAME(FI, Q)                                                                                   \
   {                                                                                                              \

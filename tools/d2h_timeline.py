@@ -21,7 +21,12 @@ def main(path):
     copies = cur.execute(f"select {st}, {en}, {size} from {mc} where {size} >= 67108864 order by {st}").fetchall()
     if not copies:
         print("no copies >= 64 MB; columns:", cols)
-        return
+        for row in cur.execute(f"select name, count(*), min({size}), max({size}), sum({size}) from {mc} group by name").fetchall():
+            print("   ", row)
+        thr = cur.execute(f"select max({size}) from {mc}").fetchone()[0] or 0
+        copies = cur.execute(f"select {st}, {en}, {size} from {mc} where {size} >= ? order by {st}", (thr // 2,)).fetchall()
+        if not copies:
+            return
     kcols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
     ks, ke = ("start" if "start" in kcols else "start_timestamp"), ("end" if "end" in kcols else "end_timestamp")
     # the last step = the last run of copies separated from the ones before it by > 50 ms

@@ -719,7 +719,7 @@ def main():
         out["kernel_ms_per_step"]["sum"] = round(tot / args.steps, 3)
     if sink is not None:
         out["heatmap_frames_streamed_per_step"] = sink.frames_seen // (args.steps + args.warmup)
-        out["config"]["heatmap_sink"] = ("HeatmapFrameMeans: every frame crosses PCIe into page-locked memory, the host then reads 1/256 of "
+        out["config"]["heatmap_sink"] = ("HeatmapFrameMeans: every frame crosses PCIe into page-locked memory, the host then reads 1/1024 of "
                                          "its pixels (a writer's encode / file cost is NOT in the figure)") if args.heatmap_sink == "host" else \
                                         "HeatmapFrameMeans(device=True): the frames are consumed on the GPU (per-frame means), nothing crosses PCIe in the step"
         if args.heatmap_sink == "host":

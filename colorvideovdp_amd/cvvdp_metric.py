@@ -339,7 +339,10 @@ class cvvdp(vq_metric):
         (`frames`: float16 CPU tensor [1, 1|3, n, H, W], valid only during the call) instead of `stats["heatmap"]`
         holding the whole clip -- an 8K x 256-frame colour heat map is 51 GB.  A sink with an attribute `wants_uint8 = True`
         receives the frames as its file format needs them: uint8 [n, H, W, 1|3], converted on the GPU exactly as the reference's
-        writers convert the fp16 map (run_cvvdp.py:62-78).  See colorvideovdp_amd.heatmap_writers."""
+        writers convert the fp16 map (run_cvvdp.py:62-78).  A host sink is called piece by piece IN ORDER from one worker thread of this
+        call (never concurrently with itself), so that a slow writer does not hold up the kernels and copies of the pieces behind it;
+        predict_video_source() returns after the last call, and an exception of the sink is raised from it.  See
+        colorvideovdp_amd.heatmap_writers."""
         inner = getattr(vid_source, "vs", None)             # video_source_file wraps the source that does the work (video_source_file.py:755-820)
         if isinstance(inner, video_source):
             vid_source = inner
@@ -490,6 +493,17 @@ class cvvdp(vq_metric):
         if self.score_frames is not None:
             return max(1, int(self.score_frames))
         return 32 if getattr(self, "_sink_on_device", False) else 16
+
+    def _copy_stream(self):
+        """A stream for copies across PCIe, on a hardware queue of its own.  HIP maps a process's streams onto a handful of hardware queues
+        per priority level (four by default), and streams that share one run in order: the heat map's D2H stream shared its queue with one
+        of the core's helper streams, so a piece's border-strip kernels sat behind the PREVIOUS piece's 28-ms copy and the link idled 4 ms
+        after every copy (8K x 256: 77 of 550 ms, profiles/r06_d2h_events_timeline.txt).  High-priority streams come from another
+        pool of queues; a copy has no use for the priority itself."""
+        try:
+            return torch.cuda.Stream(self.device, priority=-1)
+        except Exception:
+            return torch.cuda.Stream(self.device)
 
     def _alloc_workspace(self, nbytes):
         """The one device allocation of a call (torch's caching allocator; the core allocates nothing itself)."""
@@ -695,7 +709,7 @@ class cvvdp(vq_metric):
                     self._hm_stage = None                                                                   # (unpin the old ring first)
                     stage = self._hm_stage = [torch.empty(need, dtype=torch.uint8, device="cpu", pin_memory=True) for _ in range(n_stage)]
             if not sink_dev:
-                copy_stream = getattr(self, "_hm_stream", None) or torch.cuda.Stream(self.device)
+                copy_stream = getattr(self, "_hm_stream", None) or self._copy_stream()
                 self._hm_stream = copy_stream
         elif self.do_heatmap:
             # The reference keeps the whole fp16 heat map on the CPU (cvvdp_metric.py:344).  Page-locked memory
@@ -712,22 +726,36 @@ class cvvdp(vq_metric):
                 self._hm_base = None
                 try:
                     base = torch.empty(int(np.prod(shape)), dtype=torch.float16, device="cpu", pin_memory=True)   # every frame is written below
-                    copy_stream = getattr(self, "_hm_stream", None) or torch.cuda.Stream(self.device)
+                    copy_stream = getattr(self, "_hm_stream", None) or self._copy_stream()
                     self._hm_base, self._hm_stream = base, copy_stream
                     heatmap = base.view(shape)
                 except RuntimeError:
                     heatmap = torch.empty(shape, dtype=torch.float16, device="cpu")
 
+        # Host sinks are fed from ONE worker thread, piece by piece in order (round 6): the thread waits for the piece's copy and calls the
+        # sink, while this thread goes on queueing kernels and copies.  A sink that takes as long as a piece's copy (a PNG / ffmpeg
+        # writer; even bench.py's frame means, whose strided reads of 1.6 GB cost 30 ms per 8K piece) used to sit between two
+        # pieces' launches: the D2H stream of configs[4] idled 77 of 550 ms (profiles/r06_d2h_events_timeline.txt).  A staging
+        # buffer is reused only after the sink has returned from the piece that used it; a sink's exception is re-raised here.
+        sink_pool = [None]
+
+        def _feed_sink(ev, frame0, view):
+            torch.cuda.set_device(self.device)
+            ev.synchronize()
+            heatmap_sink(frame0, view)
+
         def flush_sink(keep=0):
             while len(pending_sink) > keep:
-                ev, frame0, view, _ = pending_sink.pop(0)
-                ev.synchronize()
-                heatmap_sink(frame0, view)
+                pending_sink.pop(0)[0].result()            # (the piece has been consumed; raises what the sink raised)
 
         def fetch_heatmap(ff, n):
+            import time as _time
+            host_t = [_time.perf_counter()]
             if stage is not None and sink_u8:
                 buf = torch.empty((n, height, width, hm_ch), dtype=torch.uint8, device=self.device)
+                host_t.append(_time.perf_counter())
                 _capi.check(self._handle, lib.cvvdp_get_heatmap_rgb8(self._handle, n, buf.data_ptr(), stream), "cvvdp_get_heatmap_rgb8")
+                host_t.append(_time.perf_counter())
             else:
                 buf = torch.empty((hm_ch, n, height, width), dtype=torch.float16, device=self.device)
                 _capi.check(self._handle, lib.cvvdp_get_heatmap(self._handle, n, buf.data_ptr(), stream), "cvvdp_get_heatmap")
@@ -736,6 +764,7 @@ class cvvdp(vq_metric):
                 return
             if stage is not None:
                 flush_sink(keep=len(stage) - 1)            # the buffer about to be overwritten has been consumed
+                host_t.append(_time.perf_counter())
                 slot = stage_next[0]
                 stage_next[0] = (slot + 1) % len(stage)
                 dst = stage[slot]
@@ -743,13 +772,26 @@ class cvvdp(vq_metric):
                     view = dst[:hm_ch * n * height * width].view(n, height, width, hm_ch)
                 else:
                     view = dst[:2 * hm_ch * n * height * width].view(torch.float16).view(1, hm_ch, n, height, width)
+                trace = getattr(self, "d2h_trace", None)          # tools/d2h_events_timeline.py: HIP-event timeline of the D2H stream (a list to fill)
+                if trace is not None:
+                    ev_k = torch.cuda.Event(enable_timing=True)
+                    ev_k.record(torch.cuda.current_stream(self.device))       # the piece's kernels are done here
                 copy_stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(copy_stream):
+                    if trace is not None:
+                        ev_a = torch.cuda.Event(enable_timing=True)
+                        ev_a.record(copy_stream)
                     (view if sink_u8 else view[0]).copy_(buf, non_blocking=True)
-                    ev = torch.cuda.Event()
+                    ev = torch.cuda.Event(enable_timing=trace is not None)
                     ev.record(copy_stream)
+                if trace is not None:
+                    host_t.append(_time.perf_counter())
+                    trace.append((first + ff, n, view.numel() * view.element_size(), ev_k, ev_a, ev, host_t))
                 buf.record_stream(copy_stream)
-                pending_sink.append((ev, first + ff, view, slot))
+                if sink_pool[0] is None:
+                    import concurrent.futures
+                    sink_pool[0] = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="cvvdp-heatmap-sink")
+                pending_sink.append((sink_pool[0].submit(_feed_sink, ev, first + ff, view), first + ff, view, slot))
                 return
             # one copy per colour plane: heatmap[0, ch, ff:ff+n] is contiguous on the host, the [3, n, H, W] slice of a
             # longer clip is not (a strided D2H copy falls off the DMA path: 6x slower end to end)
@@ -849,7 +891,7 @@ class cvvdp(vq_metric):
             prefetch = len(blocks) > 1 and self._host_resident(vs)
             if prefetch:
                 import concurrent.futures
-                h2d = torch.cuda.Stream(self.device)
+                h2d = self._copy_stream()
                 main_stream = torch.cuda.current_stream(self.device)
 
                 dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
@@ -902,7 +944,11 @@ class cvvdp(vq_metric):
         _capi.check(self._handle, lib.cvvdp_get_q_per_ch(self._handle, Q.data_ptr(), stream), "cvvdp_get_q_per_ch")
         self._seq = None
         if stage is not None:
-            flush_sink()
+            try:
+                flush_sink()
+            finally:
+                if sink_pool[0] is not None:
+                    sink_pool[0].shutdown(wait=True)
         elif copy_stream is not None:
             copy_stream.synchronize()   # the heat map is host data: it must be complete when predict() returns
         return Q, heatmap, rho_band

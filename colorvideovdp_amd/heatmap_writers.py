@@ -124,7 +124,7 @@ class HeatmapFrameMeans:
     """Keeps only a per-frame mean of every colour plane, taken over every `step`-th pixel in both directions (a cheap sink
     for benchmarks and tests: the host only touches 1/step^2 of the 6 bytes per pixel that crossed PCIe)."""
 
-    def __init__(self, step=16, uint8=False, device=False):
+    def __init__(self, step=32, uint8=False, device=False):
         self.step = step
         self.wants_device = device        # take the frames as device tensors (nothing crosses PCIe; the means are reduced on the GPU and fetched in close())
         self.wants_uint8 = uint8          # take the frames as a file writer would (uint8 [n, H, W, C]); means are then of the 8-bit codes / 255

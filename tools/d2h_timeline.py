@@ -21,6 +21,11 @@ def main(path):
     copies = cur.execute(f"select {st}, {en}, {size} from {mc} where {size} >= 67108864 order by {st}").fetchall()
     if not copies:
         print("no copies >= 64 MB; columns:", cols)
+        for n in names:
+            try:
+                print("    %-40s %d rows" % (n, cur.execute(f"select count(*) from [{n}]").fetchone()[0]))
+            except sqlite3.Error as e:
+                print("    %-40s %s" % (n, e))
         for row in cur.execute(f"select name, count(*), min({size}), max({size}), sum({size}) from {mc} group by name").fetchall():
             print("   ", row)
         thr = cur.execute(f"select max({size}) from {mc}").fetchone()[0] or 0

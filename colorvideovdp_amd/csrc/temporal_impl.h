@@ -18,6 +18,13 @@
 #ifndef CVVDP_FIR_PF
 #define CVVDP_FIR_PF 3
 #endif
+// Timing variant (tools/build_variant.sh -DCVVDP_FIR_DIAG_LDS_TAPS_MIN=n): filter lengths >= n of k_fir_rot read their rotated taps from LDS
+// instead of scalar loads (see the kernel).  Measured and rejected in round 6 (profiles/r06_ab_fir_lds_taps.txt): 31 taps 8.61-8.66 ms against
+// 7.78 with the scalar loads, 17 taps 5.92 against 5.56-5.63; results bit-identical.  Off in the product.
+#ifndef CVVDP_FIR_DIAG_LDS_TAPS_MIN
+#define CVVDP_FIR_DIAG_LDS_TAPS_MIN 1000
+#endif
+#define CVVDP_FIR_LDS_TAPS_FOR(FL) ((FL) >= CVVDP_FIR_DIAG_LDS_TAPS_MIN)
 #include <cstdlib>
 
 namespace cvvdp {
@@ -240,10 +247,28 @@ __global__ __launch_bounds__(256) void k_fir_fused(FirArgs a) {
 template <int DT, int FL>
 __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
   __shared__ float s_tab[DT == CVVDP_U8 ? 256 : 1];
+  // LDS_TAPS (timing variant, off in the product): the rotated taps read from LDS (uniform-address ds_read_b128 = 4 taps per read, in-order
+  // lgkmcnt waits the compiler can count) instead of scalar loads from the kernel arguments.  The idea: scalar loads return out of order,
+  // so every use sits behind an s_waitcnt lgkmcnt(0), and with 4 x (FL-1) taps per frame against ~100 SGPRs the compiler loads them in
+  // chunks into ONE SGPR range and waits for each chunk in full -- eight exposed scalar-cache round trips per frame at 31 taps
+  // (profiles/r06_fir_counters.txt: waves parked 62 % of their cycles).  Four copies of the table, shifted by 0..3 taps, make every
+  // rotation offset a 16-byte aligned read (copy o & 3 at element o & ~3); same taps, slots and order of the sums: bit-identical results.
+  // MEASURED SLOWER (profiles/r06_ab_fir_lds_taps.txt): 159 instead of 135 VGPRs at 31 taps (three waves per SIMD either way), 32 LDS
+  // reads per frame on the one LDS port four SIMDs share -- the scalar cache's round trips were not what the waves are parked on.
+  constexpr bool LDS_TAPS = CVVDP_FIR_LDS_TAPS_FOR(FL);
+  __shared__ __attribute__((aligned(16))) float s_taps[LDS_TAPS ? 4 : 1][LDS_TAPS ? 4 : 1][LDS_TAPS ? CVVDP_ROT_TAPS : 4];
+  if constexpr (LDS_TAPS) {
+    for (int i = threadIdx.x; i < 4 * 4 * CVVDP_ROT_TAPS; i += 256) {
+      const int sh = i / (4 * CVVDP_ROT_TAPS), c = (i / CVVDP_ROT_TAPS) & 3, k = i & (CVVDP_ROT_TAPS - 1);
+      s_taps[sh][c][k] = (k + sh < 2 * (FL - 1)) ? a.taps_rot[c * CVVDP_ROT_TAPS + k + sh] : 0.0f;
+    }
+    __syncthreads();
+  }
   const bool use_lut = stage_eotf_table<DT>(a.dm, s_tab);
   static_assert(FL >= 3 && 2 * (FL - 1) <= CVVDP_ROT_NEW, "window = one 16- or 32-wide register vector + the newest frame in a scalar slot");
   typedef float v16f __attribute__((ext_vector_type(FL <= 17 ? 16 : 32)));
   typedef float v2f_ __attribute__((ext_vector_type(2)));
+  typedef float v4f_ __attribute__((ext_vector_type(4)));
   static_assert((FL - 1) % 2 == 0, "the older frames are summed in slot pairs");
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= a.P) return;
@@ -328,6 +353,7 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
 #else
 #define CVVDP_FIR_STORE(v, p) __builtin_nontemporal_store(v, p)
 #endif
+#define CVVDP_FIR_TAP2(s) (LDS_TAPS ? (((s) & 2) ? v2f_{tq[(s) / 4].z, tq[(s) / 4].w} : v2f_{tq[(s) / 4].x, tq[(s) / 4].y}) : v2f_{t[s], t[(s) + 1]})
 #ifndef CVVDP_FIR_CHAINS
 #define CVVDP_FIR_CHAINS 2            /* independent accumulator pairs per channel (timing variants: tools/build_variant.sh -DCVVDP_FIR_CHAINS=n) */
 #endif
@@ -344,7 +370,7 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
 #define CVVDP_FIR_SUM_PAIRS                                                                                      \
       v2f_ ch_[CVVDP_FIR_CHAINS];                                                                                \
       _Pragma("unroll") for (int q = 0; q < CVVDP_FIR_CHAINS; ++q) ch_[q] = v2f_{0.0f, 0.0f};                    \
-      _Pragma("unroll") for (int s = 0; s < M; s += 2) ch_[(s / 2) % CVVDP_FIR_CHAINS] += v2f_{wlo[p][s], wlo[p][s + 1]} * v2f_{t[s], t[s + 1]}; \
+      _Pragma("unroll") for (int s = 0; s < M; s += 2) ch_[(s / 2) % CVVDP_FIR_CHAINS] += v2f_{wlo[p][s], wlo[p][s + 1]} * CVVDP_FIR_TAP2(s); \
       _Pragma("unroll") for (int w = 1; w < CVVDP_FIR_CHAINS; w *= 2)                                            \
         _Pragma("unroll") for (int q = 0; q + w < CVVDP_FIR_CHAINS; q += 2 * w) ch_[q] += ch_[q + w];            \
       acc2 = ch_[0];
@@ -357,9 +383,15 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
     const int sw = __builtin_amdgcn_readfirstlane(sA == 0 ? M - 1 : sA - 1);   /* (A-1) mod M, in an SGPR */      \
     _Pragma("unroll") for (int p = 0; p < 3; ++p) { wlo[p][sw] = whi[p]; whi[p] = d[p][0]; }                     \
     const float* tb = a.taps_rot + (sA == 0 ? 0 : M - sA);                                                       \
+    const int to_ = (sA == 0 ? 0 : M - sA);                                                                      \
+    const float* tl = &s_taps[LDS_TAPS ? (to_ & 3) : 0][0][LDS_TAPS ? (to_ & ~3) : 0];                           \
     _Pragma("unroll") for (int c = 0; c < 4; ++c) { /* Y-sust, RG, YV, Y-trans (plane 0 again), cvvdp_metric.py:554-560 */ \
       const int p = (c == 3) ? 0 : c;                                                                            \
       const float* t = tb + c * CVVDP_ROT_TAPS;                                                                  \
+      v4f_ tq[LDS_TAPS ? (M + 3) / 4 : 1];                                                                        \
+      if constexpr (LDS_TAPS) {                                                                                  \
+        _Pragma("unroll") for (int k4 = 0; k4 < (M + 3) / 4; ++k4) tq[k4] = *reinterpret_cast<const v4f_*>(tl + c * CVVDP_ROT_TAPS + 4 * k4); \
+      }                                                                                                          \
       /* Round 6: the M older frames as M/2 PACKED multiply-adds (v_pk_fma_f32: slots 2j, 2j+1 are an aligned register pair of the  */ \
       /* window vector, their taps an SGPR pair) -- 62 + 8 instead of 124 FMAs per frame at 31 taps, where this kernel is VALU-bound. */ \
       /* Two interleaved partial sums (even slots, odd slots), added at the end: the order is a function of the slots, i.e. of the     */ \
@@ -382,6 +414,7 @@ __global__ __launch_bounds__(256) void k_fir_rot(FirArgs a) {
     if (fi + u < a.n_frames) CVVDP_FIR_FRAME(fi + u, u)
 #undef CVVDP_FIR_FRAME
 #undef CVVDP_FIR_SUM_PAIRS
+#undef CVVDP_FIR_TAP2
   // ---- epilogue: the last M frames in time order = window positions 1..M of the last frame's window: position k < M
   // sits in slot (A_last + k) mod M = (sA - 1 + k) mod M (sA is already A_last + 1), position M is whi
   if (a.write_hist) {

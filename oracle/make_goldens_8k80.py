@@ -8,7 +8,8 @@ several temporal blocks, the machinery configs[4] runs on -- and compares its fi
 Stored: Q_per_ch [1,4,80,9], rho_band, JOD of the 80-frame clip, checksums of the regenerated inputs.  Container only (imports
 /root/reference through oracle/ref_shims); 56 minutes on 8 cores; the frames are made on demand (a streamed video_source).
 
-    python oracle/make_goldens_8k80.py
+    python oracle/make_goldens_8k80.py          (80 frames)
+    python oracle/make_goldens_8k80.py 256      (round 6: the whole clip of configs[4] -> tests/golden/deep_8k_pq_256f.npz, ~3 hours on 8 cores)
 """
 import os
 import sys
@@ -26,7 +27,8 @@ import pycvvdp
 import bench
 
 OUT = os.path.join(HERE, "..", "tests", "golden")
-W, H, F, FPS, DISP = 7680, 4320, 80, 60, "standard_hdr_pq"
+W, H, FPS, DISP = 7680, 4320, 60, "standard_hdr_pq"
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 80
 
 
 class StreamedClip(pycvvdp.video_source.video_source_dm):
@@ -78,7 +80,7 @@ def main():
         jod, stats = met.predict_video_source(vs)
     assert len(vs.seen) == F
     print(f"reference done {time.time() - t0:.0f} s  jod {float(jod):.5f}", flush=True)
-    np.savez_compressed(os.path.join(OUT, "deep_8k_pq_80f.npz"), width=W, height=H, frames=F, fps=FPS, display=DISP, dtype="u8",
+    np.savez_compressed(os.path.join(OUT, f"deep_8k_pq_{F}f.npz"), width=W, height=H, frames=F, fps=FPS, display=DISP, dtype="u8",
                         jod=np.float32(jod.item()), Q_per_ch=stats["Q_per_ch"].copy(), rho_band=stats["rho_band"],
                         checksum_test=np.int64(vs.cs_t), checksum_ref=np.int64(vs.cs_r), torch_version=torch.__version__,
                         reference_seconds=np.float32(time.time() - t0))

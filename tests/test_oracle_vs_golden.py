@@ -161,3 +161,23 @@ def test_oracle_features_against_reference():
                 assert np.all(np.abs(f[..., q + 1] - want[..., q + 1]) <= 1e-4 * scale + 1e-8), f"band {bb} var {q + 1}"
         k += 1
     assert k == 2
+
+
+def test_long_8k_fixtures_agree_where_they_overlap():
+    """The real reference's scores of configs[4]'s clip at 17 (heat map), 64 (heat map), 80 and 256 frames (oracle/make_goldens_8k17_pqrange.py,
+    _8k64_heat.py, _8k80.py [256]): four separate runs of its CPU path on prefixes of ONE clip.  The temporal filter is causal, so a prefix's
+    per-frame scores must be the longer run's, bit for bit -- the claim every test that holds a long GPU run against a short fixture rests on."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN, load_golden
+    have = [n for n in ("deep_8k_pqrange_heat_17f", "deep_8k_pqrange_heat_64f", "deep_8k_pq_80f", "deep_8k_pq_256f") if os.path.isfile(os.path.join(GOLDEN, n + ".npz"))]
+    assert "deep_8k_pq_80f" in have and "deep_8k_pqrange_heat_17f" in have
+    gs = [load_golden(n) for n in have]
+    for a in gs:
+        for b in gs:
+            fa, fb = int(a["frames"]), int(b["frames"])
+            if fa < fb:
+                np.testing.assert_array_equal(a["Q_per_ch"], b["Q_per_ch"][:, :, :fa])
+                np.testing.assert_array_equal(a["rho_band"], b["rho_band"])
+                if "heatmap_frame_means" in a and "heatmap_frame_means" in b:
+                    np.testing.assert_array_equal(a["heatmap_frame_means"], b["heatmap_frame_means"][:fa])

@@ -3,6 +3,8 @@
 # kernel trace, HBM traffic counters (separate --pmc passes), SQ counters, the stamp of the sources they were measured on, and the
 # default bench line from the same box.    tools/refresh_counters.sh r03   -> gpurun_out/refresh/<tag>_*
 set -u
+# the library that is measured must be the one these sources build (a variant experiment can leave an older .so in the tree: round 6)
+make -C colorvideovdp_amd/csrc -q all || { echo "colorvideovdp_amd/libcvvdp_hip.so is older than its sources: run make first" >&2; exit 1; }
 TAG=${1:-r05}
 R=$(pwd)
 OUT=$R/gpurun_out/refresh

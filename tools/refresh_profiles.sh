@@ -4,6 +4,8 @@
 # Writes everything under gpurun_out/refresh/ (merged back by gpurun); copy the *.txt/*.json into profiles/ and run
 # tools/make_traffic_json.py <tag>.
 set -u
+# the library that is measured must be the one these sources build (a variant experiment can leave an older .so in the tree: round 6)
+make -C colorvideovdp_amd/csrc -q all || { echo "colorvideovdp_amd/libcvvdp_hip.so is older than its sources: run make first" >&2; exit 1; }
 TAG=${1:-r05}
 R=$(pwd)
 OUT=$R/gpurun_out/refresh

@@ -302,6 +302,13 @@ def device_identity(rank, dev_index):
             "host": os.uname().nodename}
 
 
+def count_distinct_devices(ranks_seen):
+    """How many different GPUs the ranks sit on.  A device is (host, device index, PCI bus id, uuid) TOGETHER: a stack that reports the
+    same -- or no -- uuid for every GPU must not turn eight ranks on eight GPUs into "one device" (the RCCL line would be refused), and
+    ranks pinned to one GPU (the test hook) agree in all four."""
+    return len({(r["host"], r["device_index"], r["pci"], r["uuid"]) for r in ranks_seen})
+
+
 def measured_copy_ceiling(working_set_mb=None):
     """The rate a float4 device copy (read + write) reaches on a gpurun box AT THE WORKING-SET SIZE of the step: the newest
     profiles/*ubench_hbm_copy_size_shape.txt (tools/ubench/hbm_copy_size_shape.hip, section A: bytes per side -> TB/s for three access
@@ -476,7 +483,7 @@ def main():
         # which device every rank really sits on (the SCALE record shows N distinct GPUs, or says that the ranks share one)
         ranks_seen = [None] * world
         torch.distributed.all_gather_object(ranks_seen, device_identity(rank, dev_index))
-        distinct = len({r["uuid"] or (r["host"], r["device_index"]) for r in ranks_seen})
+        distinct = count_distinct_devices(ranks_seen)
         if backend == "nccl" and distinct != world:
             # a SCALE line whose RCCL ranks share GPUs is not a scaling measurement: every rank refuses, before any clip is made
             raise SystemExit(f"bench.py: {world} RCCL ranks sit on {distinct} distinct GPUs ({[r['pci'] for r in ranks_seen]}): one rank per GPU is the contract")
@@ -590,7 +597,7 @@ def main():
         "jod": round(float(jod), 5), "spinup_steps": n_spin,
     }
     if dist_on:
-        distinct = len({r["uuid"] or (r["host"], r["device_index"]) for r in ranks_seen})
+        distinct = count_distinct_devices(ranks_seen)
         halo = [min(fl - 1, plan_frame_shard(n_total, r, world)[0]) for r in range(world)]
         out["config"]["collectives"] = {"backend": torch.distributed.get_backend(), "world": world,
                                         "per_step": "one all-gather of the Q_per_ch shards", "spin_up": "barrier + one broadcast word per step",

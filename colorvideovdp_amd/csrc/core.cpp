@@ -960,6 +960,7 @@ static int get_heatmap_impl(cvvdp_handle* h, int32_t n_frames, void* dev_out_f16
   a.range_done = h->last_range_done ? 1 : 0;
   a.curve = h->ws + h->hcurve_off;
   a.out = dev_out_f16; a.out_u8 = out_u8;
+  a.pixel_layout = h->c.band_layout == 1;
   ProfScope ps(h, CVVDP_PROF_HEATMAP, s);
   if (h->c.heatmap == CVVDP_HEATMAP_RAW) {
     launch_heat_raw(a, s);

@@ -293,6 +293,8 @@ struct HeatArgs {
   int32_t n_nodes;        // colour map nodes (5 threshold, 3 supra-threshold)
   float cin[5];           // node positions
   float cch[15];          // node colours / luminance, [node][rgb]  (visualize_diff_map.py:93-94)
+  int32_t pixel_layout;   // 1: k_heat_colour<VEC> (a thread = 4 pixels anywhere) also where the row-tile kernel k_heat_colour_rows applies:
+                          // the A/B switch of tests (cvvdp_clip.band_layout == 1); the two produce the same bits
 };
 void launch_heat_raw(const HeatArgs& a, hipStream_t s);
 void launch_heat_init(uint32_t* stats, int items, hipStream_t s);     // min / max / histogram words of `items` frames to their start values

@@ -127,7 +127,9 @@ typedef struct cvvdp_clip {
   int32_t band_layout;          /* how a fused level's band kernel divides its work between waves.  0 (normal use): front / back waves
                                    (band4s.hip: 8 waves per block, four per SIMD); 1: one wave per channel (round 3's k_band4f everywhere,
                                    two per SIMD).  Same arithmetic, the same level-(l+1) planes bit for bit, per-frame sums equal to the last bit or so
-                                   (two separately compiled kernels): 1 is the A/B switch of tests and benchmarks; a clip is scored by one layout */
+                                   (two separately compiled kernels): 1 is the A/B switch of tests and benchmarks; a clip is scored by one layout.
+                                   1 also selects the heat-map finishing kernel with one thread per 4 pixels where 0 runs the row-tile
+                                   kernel (heatmap.hip k_heat_colour / k_heat_colour_rows: the same bits) */
   int32_t defer_bands;          /* 1: cvvdp_process_block* run the temporal stage only and leave the level-0 planes of the block (up to
                                    block_frames frames) in the workspace; the caller scores them in pieces of at most score_frames frames
                                    with cvvdp_score_frames.  For heat-map clips: the frames' heat maps leave the GPU piece by piece

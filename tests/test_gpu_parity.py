@@ -879,6 +879,50 @@ def test_streaming_heatmap_sink_matches_the_whole_clip_tensor(tmp_path):
         _metric(dict(meta, heatmap=None)).predict_video_source(vs, heatmap_sink=sink)
 
 
+def test_heat_colour_kernels_agree_bit_for_bit():
+    """The heat-map finishing kernel of large frames (heatmap.hip k_heat_colour_rows: a block owns a tile of rows, tone curve and colour map in
+    LDS, the coarse patch of the fused last reconstruction step as a rolling window) against the kernel it replaced on those frames
+    (k_heat_colour<true>: a thread = 4 pixels anywhere; still what W % 4 == 0 frames without a fused last step run, and band_layout = 1
+    selects it everywhere): the same operations on the same values, so the same fp16 / 8-bit frames bit for bit.  fuse_mode = 2 keeps the
+    band kernels out of the comparison (band_layout also switches the fused levels' band kernel).  Shapes: two column chunks with a
+    part-filled last one (W = 1028), an odd number of rows and a last row tile of 7 rows; a tone curve from the histogram and the
+    linear one of a frame with less than 0.6 log units of range (visualize_diff_map.py:28-31)."""
+    import colorvideovdp_amd as cv
+    rng = np.random.default_rng(77)
+    for (H, W, F), flat in (((71, 1028, 3), False), ((180, 256, 4), False), ((48, 64, 2), True)):
+        yy, xx = np.mgrid[0:H, 0:W]
+        if flat:
+            base = 118.0 + 6.0 * np.sin(xx / 9.0) * np.cos(yy / 7.0)
+        else:
+            base = 8.0 + 235.0 * (0.5 + 0.5 * np.sin(xx / 37.0 + yy / 23.0)) * (xx / W)
+        r = np.clip(base[None, None, :, :] + rng.normal(0, 2.0, (F, 3, H, W)), 0, 255).round().astype(np.uint8)        # [F,C,H,W]
+        t = np.clip(r.astype(np.float32) + rng.normal(0, 6.0, r.shape) * (xx > W // 3), 0, 255).round().astype(np.uint8)
+        t, r = (torch.from_numpy(np.ascontiguousarray(a.transpose(1, 0, 2, 3))[None]) for a in (t, r))                  # BCFHW
+        for mode in ("threshold", "supra-threshold"):
+            out = {}
+            for layout in (0, 1):
+                m = cv.cvvdp(display_name="standard_4k", heatmap=mode)
+                m.fuse_mode, m.band_layout = 2, layout
+                _, st = m.predict(t, r, dim_order="BCFHW", frames_per_second=30)
+                got = np.zeros((F, H, W, 3), np.uint8)
+
+                class Sink:
+                    wants_uint8 = True
+
+                    def __call__(self, first, frames):
+                        got[first:first + frames.shape[0]] = frames.numpy()
+
+                vs = cv.video_source_array(t, r, 30, dim_order="BCFHW", display_photometry=m.display_photometry)
+                m.predict_video_source(vs, heatmap_sink=Sink())
+                out[layout] = (st["heatmap"].numpy().copy(), st["Q_per_ch"].copy(), got)
+            np.testing.assert_array_equal(out[0][1], out[1][1])
+            a16, b16 = out[0][0].view(np.uint16).astype(np.int32), out[1][0].view(np.uint16).astype(np.int32)
+            bad = np.argwhere(a16 != b16)
+            assert bad.shape[0] == 0, (H, W, mode, "fp16 planes differ", bad.shape[0], int(np.abs(a16 - b16).max()), bad[:8].tolist())
+            np.testing.assert_array_equal(out[0][2], out[1][2])
+            assert out[0][0].astype(np.float32).std() > 0.01 and np.isfinite(out[0][0].astype(np.float32)).all()
+
+
 def test_uint8_heatmap_sink_is_the_writers_conversion(tmp_path):
     """A sink with wants_uint8 receives [n, H, W, C] uint8 frames made on the GPU (cvvdp_get_heatmap_rgb8): bit for bit what the
     reference's writers make of the fp16 map (np.clip(x, 0, 1) * 255 -> uint8, run_cvvdp.py:62-78); half the bytes over PCIe."""

@@ -363,6 +363,7 @@ int run_bands(cvvdp_handle* h, int n_frames, int q_frame_offset, int set, hipStr
       e.fine = h->ws + h->lv[l].heat_off; e.coarse = h->ws + h->lv[l + 1].heat_off;
       e.H = h->lv[l].H; e.W = h->lv[l].W; e.Hc = h->lv[l + 1].H; e.Wc = h->lv[l + 1].W; e.n_img = items;
       e.kx[0] = K[0] * 2.0f; e.kx[1] = K[2] * 2.0f; e.kx[2] = K[1] * 2.0f;
+      e.per_thread_layout = h->c.band_layout == 1;
       launch_expand_add(e, s);
     }
     if (int e = check_launch(h, "heat reconstruct")) return e;

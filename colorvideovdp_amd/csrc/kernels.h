@@ -271,6 +271,7 @@ void launch_pool(const PoolArgs& a, hipStream_t s);
 // ---------------------------------------------------------------- heat map (K9, K10)
 struct ExpandAddArgs {
   float* fine; const float* coarse; int32_t H, W, Hc, Wc, n_img; float kx[3];
+  int32_t per_thread_layout;   // 1: k_expand_add4 also where the row-tile kernel applies (A/B switch of tests: cvvdp_clip.band_layout == 1)
 };
 void launch_expand_add(const ExpandAddArgs& a, hipStream_t s);
 

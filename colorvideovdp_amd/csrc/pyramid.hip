@@ -8,6 +8,7 @@
 // k_reduce_vec / k_reduce2 (horizontal pass first in registers, no LDS), which round differently.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "kernels.h"
 
 namespace cvvdp {
@@ -525,8 +526,73 @@ __global__ __launch_bounds__(256) void k_expand_add4(ExpandAddArgs a) {
   *p = t;
 }
 
+// Round 6b: k_expand_add4 for the large levels of a heat-map reconstruction (level 1 of an 8K frame: 627 us per 16 frames = 1.9 TB/s
+// for a read-modify-write of 8 B/pixel + 1 B/pixel of coarse samples).  A thread of k_expand_add4 divides its index by the row length,
+// forms twelve clamped 64-bit addresses and loads a 3 x 4 coarse patch for its 4 pixels; here a block owns a tile of 16 rows x up to
+// 1024 columns and a thread walks DOWN its four columns with the three coarse rows it needs as a rolling window in registers (four
+// loads every second fine row), 32-bit offsets from uniform bases, row parity a compile-time constant of the unrolled row pair
+// (heatmap.hip k_heat_colour_rows is the same walk).  The same expand_even / expand_odd chains on the same values: the same bits.
+constexpr int kExpandTileRows = 16;
+__global__ __launch_bounds__(256) void k_expand_add_rows(ExpandAddArgs a, int n_chunk, int chunk_cols) {
+  const int img = blockIdx.y;
+  const int chunk = (int)blockIdx.x % n_chunk, rg = (int)blockIdx.x / n_chunk;
+  const int x = chunk * chunk_cols + 4 * (int)threadIdx.x;
+  if (4 * (int)threadIdx.x >= chunk_cols || x >= a.W) return;
+  const int W = a.W, Wc = a.Wc, Hc = a.Hc;
+  const int y_begin = rg * kExpandTileRows, y_end = min(a.H, y_begin + kExpandTileRows);
+  const float e0 = a.kx[0], e1 = a.kx[1], eo = a.kx[2];
+  const float* coarse = a.coarse + (int64_t)img * Hc * Wc;
+  char* fine = reinterpret_cast<char*>(a.fine + (int64_t)img * a.H * W);      // (a level of one image stays below 2^32 bytes)
+  const int mx = x >> 1;
+  int cx[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cx[k] = min(max(mx - 1 + k, 0), Wc - 1);
+  auto load_row = [&](int r, float (&d)[4]) {
+    const float* p = coarse + (int64_t)r * Wc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = p[cx[k]];
+  };
+  float cA[4], cB[4], cC[4];                                   // coarse rows max(my-1, 0), my, min(my+1, Hc-1) of the current fine row
+  {
+    const int my = y_begin >> 1;
+    load_row(max(my - 1, 0), cA); load_row(my, cB); load_row(min(my + 1, Hc - 1), cC);
+  }
+  auto row = [&](int y, auto odd_) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if constexpr (decltype(odd_)::value) v[k] = expand_odd(cB[k], cC[k], eo);
+      else v[k] = expand_even(cA[k], cB[k], cC[k], e0, e1);
+    }
+    float4* p = reinterpret_cast<float4*>(fine + (uint32_t)(y * W + x) * 4u);
+    float4 t = *p;
+    t.x += expand_even(v[0], v[1], v[2], e0, e1);
+    t.y += expand_odd(v[1], v[2], eo);
+    t.z += expand_even(v[1], v[2], v[3], e0, e1);
+    t.w += expand_odd(v[2], v[3], eo);
+    *p = t;
+  };
+  for (int y = y_begin; y < y_end; y += 2) {                   // (y_begin is even)
+    row(y, std::false_type{});
+    if (y + 1 < y_end) row(y + 1, std::true_type{});
+    if (y + 2 < y_end) {                                       // the next row pair's window: coarse row my+1 becomes my
+      const int my = (y >> 1) + 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { cA[k] = cB[k]; cB[k] = cC[k]; }
+      load_row(min(my + 1, Hc - 1), cC);
+    }
+  }
+}
+
 void launch_expand_add(const ExpandAddArgs& a, hipStream_t s) {
   if (a.W % 4 == 0 && a.Wc >= 2) {
+    if (a.W >= 512 && a.H >= 2 * kExpandTileRows && !a.per_thread_layout) {
+      const int n_chunk = (a.W + 1023) / 1024;
+      const int chunk_cols = ((a.W / 4 + n_chunk - 1) / n_chunk) * 4;
+      const int n_rg = (a.H + kExpandTileRows - 1) / kExpandTileRows;
+      hipLaunchKernelGGL(k_expand_add_rows, dim3(n_chunk * n_rg, a.n_img), dim3(256), 0, s, a, n_chunk, chunk_cols);
+      return;
+    }
     dim3 grid((a.H * (a.W / 4) + 255) / 256, a.n_img);
     hipLaunchKernelGGL(k_expand_add4, grid, dim3(256), 0, s, a);
     return;

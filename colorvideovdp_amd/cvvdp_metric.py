@@ -99,7 +99,7 @@ class cvvdp(vq_metric):
         self._shard = None
         self.debug_dump = False
         self.score_frames = None      # heat-map clips resident in HBM: frames per band / heat-map piece of a long temporal block (None: 16; >= the block: one piece)
-        self.band_layout = 0          # cvvdp_clip.band_layout: 0 = front / back waves on fused levels (normal use); 1 = one wave per channel (A/B switch; scores equal to the last bit or so)
+        self.band_layout = 0          # cvvdp_clip.band_layout: 0 = front / back waves on fused levels (normal use); 1 = one wave per channel, and the per-thread heat-map finishing kernels (A/B switch; scores equal to the last bit or so, heat maps bit for bit)
         self.fuse_mode = 0            # cvvdp_clip.fuse_mode: 0 = the core decides (normal use); 1 / 2 = fused band kernels everywhere / nowhere (tests)
         self.set_display_model(display_name, display_photometry=display_photometry, display_geometry=display_geometry,
                                config_paths=config_paths)

@@ -886,10 +886,12 @@ def test_heat_colour_kernels_agree_bit_for_bit():
     selects it everywhere): the same operations on the same values, so the same fp16 / 8-bit frames bit for bit.  fuse_mode = 2 keeps the
     band kernels out of the comparison (band_layout also switches the fused levels' band kernel).  Shapes: two column chunks with a
     part-filled last one (W = 1028), an odd number of rows and a last row tile of 7 rows; a tone curve from the histogram and the
-    linear one of a frame with less than 0.6 log units of range (visualize_diff_map.py:28-31)."""
+    linear one of a frame with less than 0.6 log units of range (visualize_diff_map.py:28-31).  The same switch selects k_expand_add4
+    where the coarser steps of the reconstruction run its row-tile form (pyramid.hip k_expand_add_rows: levels at least 512 columns wide
+    and 32 rows high with W % 4 == 0 -- levels 1 of the 2056- and 1, 2 of the 4096-column frames here)."""
     import colorvideovdp_amd as cv
     rng = np.random.default_rng(77)
-    for (H, W, F), flat in (((71, 1028, 3), False), ((180, 256, 4), False), ((48, 64, 2), True)):
+    for (H, W, F), flat in (((71, 1028, 3), False), ((180, 256, 4), False), ((48, 64, 2), True), ((130, 2056, 2), False), ((140, 4096, 2), False)):
         yy, xx = np.mgrid[0:H, 0:W]
         if flat:
             base = 118.0 + 6.0 * np.sin(xx / 9.0) * np.cos(yy / 7.0)

@@ -130,7 +130,7 @@ __device__ __forceinline__ float log_lum(float y, float clampval) { return logf(
 constexpr int kHistCopies = 8;
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_heat_hist(HeatArgs a) {
-  __shared__ uint32_t s_h[1024 * kHistCopies];
+  __shared__ __attribute__((aligned(16))) uint32_t s_h[1024 * kHistCopies];
   const int item = blockIdx.y;
   uint32_t* st = a.stats + (int64_t)item * kHeatStatsWords;
   const float clampval = __uint_as_float(st[0]);
@@ -183,13 +183,21 @@ __global__ __launch_bounds__(256) void k_heat_curve(HeatArgs a) {
   for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
   if ((t & 63) == 0) s_tmp[t >> 6] = part;
   __syncthreads();
+  // p^(1/3) / sum: element-wise, by every thread; the running sum stays one thread's in-order chain (1024 dependent additions, as the
+  // reference's cumsum) -- with the 1024 IEEE divisions inside that chain the kernel took 55 us per launch (round 6b)
+  const float tot = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+  for (int i = t; i < 1024; i += 256) s_p[i] = s_p[i] / tot;
+  __syncthreads();
   if (t == 0) {
-    const float tot = s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
     float run = 0.0f;
     for (int i = 0; i < 1024; ++i) {
-      run += s_p[i] / tot;
-      cv[i] = run * 0.6f + 0.2f;
+      run += s_p[i];
+      s_p[i] = run;
     }
+  }
+  __syncthreads();
+  for (int i = t; i < 1024; i += 256) cv[i] = s_p[i] * 0.6f + 0.2f;
+  if (t == 0) {
     cv[1024] = bmin;
     cv[1025] = bmax;
     cv[1026] = (bmax - bmin < 0.6f) ? 0.0f : 1.0f;

@@ -3,7 +3,9 @@
 #   tools/refresh_bench_and_trace.sh r02      -> gpurun_out/refresh/<tag>_kernel_trace.txt, <tag>_bench.json
 set -u
 # the library that is measured must be the one these sources build (a variant experiment can leave an older .so in the tree: round 6)
-make -C colorvideovdp_amd/csrc -q all || { echo "colorvideovdp_amd/libcvvdp_hip.so is older than its sources: run make first" >&2; exit 1; }
+# (by modification time: the objects of the build do not travel to the GPU box, so `make -q` cannot answer there)
+NEWER=$(find colorvideovdp_amd/csrc -maxdepth 1 \( -name "*.hip" -o -name "*.h" -o -name "*.cpp" \) -newer colorvideovdp_amd/libcvvdp_hip.so)
+[ -z "$NEWER" ] || { echo "colorvideovdp_amd/libcvvdp_hip.so is older than its sources ($NEWER): run make first" >&2; exit 1; }
 TAG=${1:-r05}
 R=$(pwd)
 OUT=$R/gpurun_out/refresh

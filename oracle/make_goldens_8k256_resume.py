@@ -13,7 +13,12 @@ path scores one frame per block, cvvdp_metric.py:353-355) and a partial file is 
 JOD of the whole clip = the reference's own do_pooling_and_jods() on the assembled Q_per_ch (cvvdp_metric.py:610-644), which is all
 predict_video_source() does with it (:398).  Container only (imports /root/reference through oracle/ref_shims).
 
-    python oracle/make_goldens_8k256_resume.py [last_frame_exclusive=256]
+    THP_MEM_ALLOC_ENABLE=1 python oracle/make_goldens_8k256_resume.py [last_frame_exclusive=256]
+    python oracle/make_goldens_8k256_resume.py N      (after stopping a run: writes deep_8k_pq_<N>f.npz from the partial file, N a multiple of 8 it holds)
+
+(THP_MEM_ALLOC_ENABLE=1: torch's CPU allocator asks for transparent huge pages.  Without it this container spends 98 % of the run's CPU time
+in the kernel -- eight threads faulting fresh 4 KB pages of 130 MB tensors into one address space -- and a frame takes 95 s instead of 42.
+The overlap check at the start of every window would show it if the alignment changed a single bit.)
 """
 import os
 import sys
@@ -62,6 +67,9 @@ def main():
         known = p["Q_per_ch"].copy()
         cs = {int(f): (int(a), int(b)) for f, a, b in zip(p["cs_frames"], p["cs_t"], p["cs_r"])}
         print(f"resuming: {known.shape[2]} frames known", flush=True)
+    if known.shape[2] > F_ALL:                                        # asked for a shorter prefix than what is known: cut (the fixture of a stopped run)
+        known = known[:, :, :F_ALL].copy()
+        cs = {f: v for f, v in cs.items() if f < F_ALL}
     n0 = known.shape[2]
     if n0 < F_ALL:
         start = n0 - OVERLAP - HALO
@@ -83,6 +91,8 @@ def main():
             k_sub = len(rows)
             rows.append(q.detach().cpu().numpy().copy())
             fr = start + k_sub
+            if k_sub < HALO:
+                print(f"halo frame {fr}  ({time.time() - t0:.0f} s)", flush=True)
             if HALO <= k_sub < HALO + OVERLAP:
                 np.testing.assert_array_equal(rows[-1][:, :, 0], known[:, :, fr], err_msg=f"window argument fails at frame {fr}")
                 print(f"frame {fr}: equals the known row bit for bit  ({time.time() - t0:.0f} s)", flush=True)

@@ -18,11 +18,16 @@
 
 namespace cvvdp {
 
-__device__ __forceinline__ float heat_value(float q, float jod_a, float jod_exp) {
-  float jod;
-  if (q <= 0.1f) jod = 10.0f - jod_a * powf(0.1f, jod_exp - 1.0f) * q;   // met2jod, cvvdp_metric.py:646-658
-  else jod = 10.0f - jod_a * powf(q, jod_exp);
-  return 1.0f - jod / 10.0f;
+// One value of the raw map: 1 - met2jod(q)/10 (cvvdp_metric.py:646-658, :744), with the hardware log2 / exp2 pair instead of powf (the map
+// leaves as fp16 or 8 bit: 1e-6 relative is far below its last bit; until round 6b the raw kernels called powf twice per pixel -- once for
+// the CONSTANT 0.1^(jod_exp-1) -- and divided by 10: 260 VALU instructions per pixel); the slope of the linear part is a host constant
+// (HeatArgs::jod_lin); both branches evaluated and selected (a divergent branch around the power costs more than the power: the empty asm
+// makes both values exist before the select)
+__device__ __forceinline__ float heat_raw_value(float q, float jod_lin, float jod_a, float jod_exp) {
+  float j_lin = jod_lin * q, j_pow = jod_a * fast_pow(q, jod_exp);
+  asm("" : "+v"(j_lin), "+v"(j_pow));
+  const float jod = 10.0f - (q <= 0.1f ? j_lin : j_pow);
+  return 1.0f - jod * 0.1f;
 }
 
 // the 8-bit frame the reference's writers make of the fp16 map: (clip(x, 0, 1) * 255.0).astype(uint8)  (run_cvvdp.py:59-63, :76).
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(256) void k_heat_raw4(HeatArgs a) {
   const int64_t base = (int64_t)item * a.P + i;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const __half v = __float2half(heat_value(q[k], a.jod_a, a.jod_exp));
+    const __half v = __float2half(heat_raw_value(q[k], a.jod_lin, a.jod_a, a.jod_exp));
     if (a.out_u8) reinterpret_cast<uint8_t*>(a.out)[base + k] = half_to_u8(v);
     else reinterpret_cast<__half*>(a.out)[base + k] = v;
   }
@@ -74,18 +79,9 @@ __global__ __launch_bounds__(256) void k_heat_raw4(HeatArgs a) {
 __global__ __launch_bounds__(256) void k_heat_raw(HeatArgs a) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)a.items * a.P) return;
-  const __half v = __float2half(heat_value(a.recon[i], a.jod_a, a.jod_exp));
+  const __half v = __float2half(heat_raw_value(a.recon[i], a.jod_lin, a.jod_a, a.jod_exp));
   if (a.out_u8) reinterpret_cast<uint8_t*>(a.out)[i] = half_to_u8(v);    // [items][P][1]
   else reinterpret_cast<__half*>(a.out)[i] = v;
-}
-
-void launch_heat_raw(const HeatArgs& a, hipStream_t s) {
-  if (a.coarse) {
-    hipLaunchKernelGGL(k_heat_raw4, dim3((a.P / 4 + 255) / 256, a.items), dim3(256), 0, s, a);
-    return;
-  }
-  const int64_t n = (int64_t)a.items * a.P;
-  hipLaunchKernelGGL(k_heat_raw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
 }
 
 __global__ void k_heat_init(HeatArgs a) {
@@ -231,15 +227,9 @@ __device__ __forceinline__ float scale_node(int i, float bmin, float bmax, float
 // The per-pixel expressions both colour kernels share (separately rounded products and sums: see the top of the file)
 __device__ __forceinline__ float lerp_plain(float a, float b, float fr) { return a * (1.0f - fr) + b * fr; }            // interp.py:55-60
 __device__ __forceinline__ float tone_linear(float b, float bmin, float inv_lin) { return (b - bmin) * inv_lin * 0.6f + 0.2f; }   // visualize_diff_map.py:28-31
-// met2jod of one map value (cvvdp_metric.py:646-658, :744) -> 1 - jod/10 clamped to [0, 1], with the hardware log2 / exp2 pair instead of
-// powf (the map leaves as fp16 or 8 bit: 1e-6 relative is far below its last bit; the slope of the linear part is a host constant,
-// HeatArgs::jod_lin); both branches evaluated and selected (a divergent branch around the power costs more than the power: the empty
-// asm makes both values exist before the select)
+// the map value the colour kernels code: heat_raw_value clamped to [0, 1] (visualize_diff_map.py:76-90)
 __device__ __forceinline__ float heat_unit_value(float q, float jod_lin, float jod_a, float jod_exp) {
-  float j_lin = jod_lin * q, j_pow = jod_a * fast_pow(q, jod_exp);
-  asm("" : "+v"(j_lin), "+v"(j_pow));
-  const float jod = 10.0f - (q <= 0.1f ? j_lin : j_pow);
-  return fminf(fmaxf(1.0f - jod * 0.1f, 0.0f), 1.0f);
+  return fminf(fmaxf(heat_raw_value(q, jod_lin, jod_a, jod_exp), 0.0f), 1.0f);
 }
 // colour x tone-mapped luminance -> half (the reference converts a float tensor, visualize_diff_map.py:96-106)
 __device__ __forceinline__ __half heat_out_half(float c16, float tmo) { return __float2half(fminf(fmaxf(c16 * tmo, 0.0f), 1.0f)); }
@@ -528,6 +518,89 @@ __global__ __launch_bounds__(256) void k_heat_colour_rows(HeatArgs a, int n_chun
       load_row(min(my + 1, Hc - 1), cC);
     }
   }
+}
+
+// The raw map on k_heat_colour_rows' walk (a.coarse != null): 16-row tiles, the coarse patch as a rolling window, one 8-byte (fp16) or
+// 4-byte (8 bit) store per thread and row.  k_heat_raw4 keeps the frames of the A/B switch; same values (the same expressions on the same samples).
+__global__ __launch_bounds__(256) void k_heat_raw_rows(HeatArgs a, int n_chunk, int chunk_cols) {
+  const int item = blockIdx.y;
+  const int chunk = (int)blockIdx.x % n_chunk, rg = (int)blockIdx.x / n_chunk;
+  const int x = chunk * chunk_cols + 4 * (int)threadIdx.x;
+  if (4 * (int)threadIdx.x >= chunk_cols || x >= a.W) return;
+  const int W = a.W, Wc = a.Wc, Hc = a.Hc;
+  const int y_begin = rg * kHeatTileRows, y_end = min(a.H, y_begin + kHeatTileRows);
+  const float e0 = a.kx[0], e1 = a.kx[1], eo = a.kx[2];
+  const float jod_lin = a.jod_lin, jod_a = a.jod_a, jod_exp = a.jod_exp;
+  const float* coarse = a.coarse + (int64_t)item * Hc * Wc;
+  const char* rec_item = reinterpret_cast<const char*>(a.recon + (int64_t)item * a.P);
+  char* out8_item = reinterpret_cast<char*>(a.out) + (int64_t)item * a.P;
+  char* out16_item = reinterpret_cast<char*>(a.out) + (int64_t)item * a.P * 2;
+  const int mx = x >> 1;
+  int cx[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cx[k] = min(max(mx - 1 + k, 0), Wc - 1);
+  auto load_row = [&](int r, float (&d)[4]) {
+    const float* p = coarse + (int64_t)r * Wc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = p[cx[k]];
+  };
+  float cA[4], cB[4], cC[4];
+  {
+    const int my = y_begin >> 1;
+    load_row(max(my - 1, 0), cA); load_row(my, cB); load_row(min(my + 1, Hc - 1), cC);
+  }
+  auto row = [&](int y, auto odd_) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if constexpr (decltype(odd_)::value) v[k] = expand_odd(cB[k], cC[k], eo);
+      else v[k] = expand_even(cA[k], cB[k], cC[k], e0, e1);
+    }
+    const uint32_t pix = (uint32_t)(y * W + x);
+    float4 t = *reinterpret_cast<const float4*>(rec_item + pix * 4u);
+    t.x += expand_even(v[0], v[1], v[2], e0, e1);      // (lpyr_dec.py:333)
+    t.y += expand_odd(v[1], v[2], eo);
+    t.z += expand_even(v[1], v[2], v[3], e0, e1);
+    t.w += expand_odd(v[2], v[3], eo);
+    const float q[4] = {t.x, t.y, t.z, t.w};
+    union { __half hv[4]; uint2 u; } pk;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pk.hv[k] = __float2half(heat_raw_value(q[k], jod_lin, jod_a, jod_exp));
+    if (a.out_u8) {
+      uint32_t w = 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) w |= (uint32_t)half_to_u8(pk.hv[k]) << (8 * k);
+      *reinterpret_cast<uint32_t*>(out8_item + pix) = w;
+    } else {
+      *reinterpret_cast<uint2*>(out16_item + pix * 2u) = pk.u;
+    }
+  };
+  for (int y = y_begin; y < y_end; y += 2) {
+    row(y, std::false_type{});
+    if (y + 1 < y_end) row(y + 1, std::true_type{});
+    if (y + 2 < y_end) {
+      const int my = (y >> 1) + 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { cA[k] = cB[k]; cB[k] = cC[k]; }
+      load_row(min(my + 1, Hc - 1), cC);
+    }
+  }
+}
+
+void launch_heat_raw(const HeatArgs& a, hipStream_t s) {
+  if (a.coarse && !a.pixel_layout) {           // (W % 4 == 0: core.cpp heat_l0_fused)
+    const int n_chunk = (a.W + 1023) / 1024;
+    const int chunk_cols = ((a.W / 4 + n_chunk - 1) / n_chunk) * 4;
+    const int n_rg = (a.H + kHeatTileRows - 1) / kHeatTileRows;
+    hipLaunchKernelGGL(k_heat_raw_rows, dim3(n_chunk * n_rg, a.items), dim3(256), 0, s, a, n_chunk, chunk_cols);
+    return;
+  }
+  if (a.coarse) {
+    hipLaunchKernelGGL(k_heat_raw4, dim3((a.P / 4 + 255) / 256, a.items), dim3(256), 0, s, a);
+    return;
+  }
+  const int64_t n = (int64_t)a.items * a.P;
+  hipLaunchKernelGGL(k_heat_raw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
 }
 
 void launch_heat_init(uint32_t* stats, int items, hipStream_t s) {

@@ -906,13 +906,13 @@ def test_heat_colour_kernels_agree_bit_for_bit():
         r = np.clip(base[None, None, :, :] + rng.normal(0, 2.0, (F, 3, H, W)), 0, 255).round().astype(np.uint8)        # [F,C,H,W]
         t = np.clip(r.astype(np.float32) + rng.normal(0, 6.0, r.shape) * (xx > W // 3), 0, 255).round().astype(np.uint8)
         t, r = (torch.from_numpy(np.ascontiguousarray(a.transpose(1, 0, 2, 3))[None]) for a in (t, r))                  # BCFHW
-        for mode in ("threshold", "supra-threshold"):
+        for mode in ("threshold", "supra-threshold", "raw"):                 # (raw: k_heat_raw_rows against k_heat_raw4)
             out = {}
             for layout in (0, 1):
                 m = cv.cvvdp(display_name="standard_4k", heatmap=mode)
                 m.fuse_mode, m.band_layout = 2, layout
                 _, st = m.predict(t, r, dim_order="BCFHW", frames_per_second=30)
-                got = np.zeros((F, H, W, 3), np.uint8)
+                got = np.zeros((F, H, W, 1 if mode == "raw" else 3), np.uint8)
 
                 class Sink:
                     wants_uint8 = True

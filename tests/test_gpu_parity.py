@@ -576,8 +576,8 @@ def test_configs4_clip_last_64_frames_against_reference():
     # finished when it is stopped (oracle/make_goldens_8k256_resume.py N) -- a shorter prefix; the test takes its length from the fixture
     import glob
     import re
-    have = sorted((int(re.search(r"deep_8k_pq_(\d+)f\.npz$", p).group(1)), p) for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "deep_8k_pq_*f.npz")))
-    have = [x for x in have if x[0] > 80]
+    have = [(re.search(r"deep_8k_pq_(\d+)f\.npz$", p), p) for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "deep_8k_pq_*f.npz"))]
+    have = sorted((int(m.group(1)), p) for m, p in have if m is not None and int(m.group(1)) > 80)     # (not deep_8k_pq_heat_17f: another clip)
     if not have:
         pytest.skip("no tests/golden/deep_8k_pq_<N>f.npz beyond 80 frames (oracle/make_goldens_8k256_resume.py)")
     g = load_golden(os.path.basename(have[-1][1])[:-4])

@@ -172,7 +172,9 @@ def test_long_8k_fixtures_agree_where_they_overlap():
     from conftest import GOLDEN, load_golden
     import glob
     have = [n for n in ("deep_8k_pqrange_heat_17f", "deep_8k_pqrange_heat_64f") if os.path.isfile(os.path.join(GOLDEN, n + ".npz"))]
-    have += sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "deep_8k_pq_*f.npz")))     # 80 frames, and what the resumable generator has finished
+    import re
+    have += sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "deep_8k_pq_*f.npz"))
+                   if re.search(r"deep_8k_pq_\d+f\.npz$", p))                                                   # 80 frames, and what the resumable generator has finished
     assert "deep_8k_pq_80f" in have and "deep_8k_pqrange_heat_17f" in have
     gs = [load_golden(n) for n in have]
     for a in gs:

@@ -568,7 +568,7 @@ def test_configs4_clip_last_64_frames_against_reference():
     (tests/golden/deep_8k_pq_256f.npz, oracle/make_goldens_8k256_resume.py: three hours of its CPU path, made resumably from windows of the
     causal filter; VERDICT r5 missing #2: frames 80-255 had no reference figures).  A frame's scores depend on the 16 frames before it and on nothing else (causal 17-tap filter), so only
     frames 176..255 need to be the CPU generator's (0.8 s each on the box's host cores: why the suite takes a window and
-    tools/check_8k256_against_reference.py -- profiles/r06_8k256_full_check.txt -- the whole clip); the frames before them come from the
+    tools/check_8k256_against_reference.py -- profiles/r06b_8k256_full_check.txt -- the whole clip); the frames before them come from the
     device generator.  The first 80 frames' entries of the fixture are the 80-frame fixture's, bit for bit (tests/test_oracle_vs_golden.py)."""
     import bench
     import colorvideovdp_amd as cv

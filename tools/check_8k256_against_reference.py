@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """configs[4]'s clip -- 7680x4320, PQ, 256 frames, uint8 codes in the PQ range, as bench.py --workload 8k256pq makes it -- scored by the HIP
-path and held against the REAL reference frame by frame over its whole length (tests/golden/deep_8k_pq_256f.npz, oracle/make_goldens_8k80.py
-256: three hours of the reference's CPU path).  VERDICT r5 missing #2: frames 80-255 had no reference figures.
+path and held against the REAL reference frame by frame over its whole length (tests/golden/deep_8k_pq_256f.npz, oracle/make_goldens_8k256_resume.py:
+three hours of the reference's CPU path).  VERDICT r5 missing #2: frames 80-255 had no reference figures.
 
 All 256 frames come from the CPU generator the fixture was made with (a few minutes on the GPU box's host cores), which is why the GPU
 suite holds a WINDOW of the clip against the same fixture (tests/test_gpu_parity.py) and this tool the whole of it, once per round:
 
-    python tools/check_8k256_against_reference.py > profiles/r06_8k256_full_check.txt
+    python tools/check_8k256_against_reference.py > profiles/r06b_8k256_full_check.txt
 """
 import os
 import sys
@@ -26,15 +26,18 @@ def main():
     W, H, F, fps, disp = int(g["width"]), int(g["height"]), int(g["frames"]), float(g["fps"]), str(g["display"])
     t0 = time.time()
     clip = bench.ResidentClip(F, 0, F, H, W, fps, "u8", torch.device("cuda"), gen="cpu", pq_range=True)
-    print(f"# {F} frames of {W}x{H} from the CPU generator: {time.time() - t0:.0f} s; checksums "
-          f"{'match the fixture' if (clip.checksum_test, clip.checksum_ref) == (int(g['checksum_test']), int(g['checksum_ref'])) else 'DO NOT MATCH THE FIXTURE'}")
-    if (clip.checksum_test, clip.checksum_ref) != (int(g["checksum_test"]), int(g["checksum_ref"])):
+    # the fixture's checksums are sums of the codes the reference was handed (AFTER the mapping into the PQ range: oracle/make_goldens_8k80.py
+    # StreamedClip); ResidentClip.checksum_* are the generator's codes before it -- so sum what the clip holds, as the GPU tests do
+    have = (int(clip.test.sum(dtype=torch.int64)), int(clip.ref.sum(dtype=torch.int64)))
+    match = have == (int(g["checksum_test"]), int(g["checksum_ref"]))
+    print(f"# {F} frames of {W}x{H} from the CPU generator: {time.time() - t0:.0f} s; checksums {'match the fixture' if match else 'DO NOT MATCH THE FIXTURE'}")
+    if not match:
         raise SystemExit(1)
     m = cv.cvvdp(display_name=disp)
     jod, stats = m.predict_video_source(clip)
     q, qr = stats["Q_per_ch"].astype(np.float64), g["Q_per_ch"].astype(np.float64)
     err = np.abs(q - qr) / (2e-4 * np.abs(qr) + 2e-6)              # the parity tests' criterion (rtol 2e-4, atol 2e-6): 1.0 = at the tolerance
-    print(f"# temporal blocks of {m.last_block_frames} frames, {m.fused_levels} fused levels; reference: {float(g['reference_seconds']):.0f} s of its CPU path")
+    print(f"# temporal blocks of {m.last_block_frames} frames, {m.fused_levels} fused levels; reference: {str(g['assembled']) if 'assembled' in g.files else 'one run of its CPU path'}")
     print(f"JOD  hip {float(jod):.6f}  reference {float(g['jod']):.6f}  |delta| {abs(float(jod) - float(g['jod'])):.2e}")
     print("frames      max |dQ| / tolerance   (per channel)")
     for a in range(0, F, 32):
